@@ -1,0 +1,185 @@
+/*
+ * libptamd -- C ABI of the MI355X (gfx950) hot path of the path tracer:
+ * acceleration-structure build (bounds, scene box, Morton codes, radix sort,
+ * binary-radix-tree topology, bottom-up refit) and the path-trace kernel
+ * (BVH traversal, triangle tests, BSDF sampling, progressive accumulation).
+ *
+ * It replaces the D3D11 seam of the reference -- the ShaderManager /
+ * BufferManager base classes of `RayTracer` (reference: ray_tracer.hpp:7-78,
+ * buffer_manager.hpp:21-31, shader_manager.hpp:10-12) and the Dispatch /
+ * CopyResource / Map calls in ray_tracer.cpp:263-335 -- with a headless HIP
+ * layer.  Plain pointers and sizes only; nothing throws across the boundary.
+ *
+ * Conventions
+ *  - every call returns PT_OK (0) or a negative pt_status; pt_last_error()
+ *    returns the message of the most recent failure on that context;
+ *  - a context belongs to one GPU and is used from one thread at a time (the
+ *    reference is single-threaded on the immediate context);
+ *  - work is enqueued on the context's stream (pt_set_stream) and is
+ *    asynchronous unless the call downloads to host memory;
+ *  - all layouts are those of include/ptamd_structs.h.
+ */
+#ifndef PTAMD_H
+#define PTAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "ptamd_structs.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pt_context pt_context;
+
+typedef enum pt_status {
+    PT_OK = 0,
+    PT_ERR_INVALID = -1,      /* bad argument / call order            */
+    PT_ERR_HIP = -2,          /* a HIP runtime call failed            */
+    PT_ERR_NO_DEVICE = -3,    /* no usable gfx950 device              */
+    PT_ERR_UNSUPPORTED = -4   /* input outside what the path supports */
+} pt_status;
+
+/* ---- context ------------------------------------------------------------
+ * replaces: DXUTGetD3D11Device()/immediate context acquisition in
+ * buffer_manager.cpp:259 ff. and RayTracer::release (ray_tracer.cpp:351-355). */
+int         pt_create(int device_ordinal, pt_context **out);
+void        pt_destroy(pt_context *ctx);
+const char *pt_last_error(const pt_context *ctx);     /* ctx may be NULL: last create error */
+/* hipStream_t as void*; NULL = the default stream */
+int         pt_set_stream(pt_context *ctx, void *hip_stream);
+int         pt_synchronize(pt_context *ctx);
+const char *pt_version(void);
+
+/* ---- scene upload ---------------------------------------------------------
+ * replaces: addSRV(sizeof(PrimitiveRender), n, renderer_primitives.data())
+ * (ray_tracer.cpp:144-147).  Host or device memory, n >= 1. */
+int pt_upload_primitives(pt_context *ctx, const pt_PrimitiveRender *host_prims, int n);
+int pt_upload_primitives_device(pt_context *ctx, const void *dev_prims, int n);
+/* replaces: the per-frame Map/write of constant_buffers_[0] (CS.cpp:405-439).
+ * node_count must equal the primitive count. */
+int pt_set_constants(pt_context *ctx, const pt_CB_Radix *cb);
+
+/* ---- build ----------------------------------------------------------------
+ * replaces: the CPU half of RayTracer::loadScene (AABBs, scene box, Morton
+ * codes, sort, strip: ray_tracer.cpp:41-66), RayTracer::buildRadixTree
+ * (ray_tracer.cpp:263-269 -> radix_build_cs.hlsl) and RayTracer::buildBVH
+ * (ray_tracer.cpp:271-279 -> bvh_build_cs.hlsl).
+ * Equal Morton codes keep ascending primitive index (stable sort). */
+#define PT_BUILD_DEFAULT        0u
+#define PT_BUILD_MORTON_FULL    1u   /* NON-PARITY: quantise to 2^21 cells per axis instead of the reference's 22 */
+#define PT_BUILD_NO_TREE_EXPORT 2u   /* skip writing the reference-layout TreeNode[2n] array (kept: the traversal layout) */
+int pt_build(pt_context *ctx, unsigned flags);
+
+typedef enum pt_build_stage {
+    PT_STAGE_BOUNDS = 0,   /* per-triangle AABB + scene box   */
+    PT_STAGE_MORTON,       /* Morton codes                    */
+    PT_STAGE_SORT,         /* radix sort (all passes)         */
+    PT_STAGE_TOPOLOGY,     /* binary radix tree links         */
+    PT_STAGE_REFIT,        /* leaf init + bottom-up AABBs     */
+    PT_STAGE_PACK,         /* triangle records for traversal  */
+    PT_STAGE_COUNT
+} pt_build_stage;
+/* device-side durations (ms, HIP events) of the last pt_build; total = sum.
+ * Synchronises the stream. */
+int pt_build_times(pt_context *ctx, float stage_ms[PT_STAGE_COUNT], float *total_ms, int *sort_passes);
+
+/* downloads of build products in the reference layouts (each synchronises) */
+int pt_download_scene_bound(pt_context *ctx, pt_Bound *bb);             /* RayTracer::bb_               */
+int pt_download_morton(pt_context *ctx, uint64_t *codes /* n, primitive order */);
+int pt_download_permutation(pt_context *ctx, int32_t *perm /* n, sorted position -> primitive */);
+int pt_download_sorted_primitives(pt_context *ctx, pt_PrimitiveRayCS *out /* n: ray_cs_primitives */);
+int pt_download_tree(pt_context *ctx, pt_TreeNode *out /* 2n: tree_uav */);
+
+/* ---- images -----------------------------------------------------------------
+ * replaces: RayTracer::resize (ray_tracer.cpp:188-261): (re)creates the
+ * accumulation / display / G-buffer images and resets the frame counter. */
+int pt_resize(pt_context *ctx, int width, int height);
+/* replaces: CopyResource(RT0/1/2 -> gbuffer/gbuffer2/gbuffer3) (CS.cpp:369-390):
+ * colour RGBA8 (the bytes the shader samples as UNORM), normal.xyz + asfloat(matid+1)
+ * RGBA32F, world position RGBA32F; row-major, width*height texels each. */
+int pt_upload_gbuffer(pt_context *ctx, const uint8_t *diffuse_rgba8, const float *normal_matid_rgba32f,
+                      const float *worldpos_rgba32f);
+int pt_download_gbuffer(pt_context *ctx, uint8_t *diffuse_rgba8, float *normal_matid_rgba32f,
+                        float *worldpos_rgba32f);
+
+typedef struct pt_camera {
+    float eye[3], at[3], up[3];
+    float fovy, znear, zfar;
+} pt_camera;
+/* stands in for: the rasterised G-buffer pass (fixed_pipeline.hlsl:49-67,
+ * CS.cpp:309-393): casts one ray per pixel centre.  albedo_rgba8[16][4] are the
+ * bytes the colour target holds per material (pt_albedo_bytes computes them). */
+int  pt_primary_hits(pt_context *ctx, const pt_camera *cam, const uint8_t *albedo_rgba8);
+void pt_albedo_bytes(const float kd[3], int srgb_quirk, uint8_t out_rgb[3]);
+
+/* ---- trace --------------------------------------------------------------------
+ * replaces: RayTracer::trace (ray_tracer.cpp:281-335 -> ray_tracing.hlsl:CSMain)
+ * including the CopyResource(old <- output) and frame_count += 1.
+ * One call = one frame: 1 path per pixel, literal accumulate
+ *   out = pow(pow(old, 2.2) * f/(f+1) + sample/(f+1), 1/2.2),  f = framecount.
+ * `seed` is g_random[0] of that frame. */
+int pt_trace(pt_context *ctx, uint32_t framecount, uint32_t seed);
+/* `count` consecutive frames first_frame .. first_frame+count-1 in ONE launch,
+ * each pixel running its frames back to back; seeds[i] belongs to frame
+ * first_frame+i (host pointer).  mode PT_ACCUM_LITERAL gives exactly the images
+ * `count` pt_trace calls give; PT_ACCUM_LINEAR adds the linear samples into a
+ * float RGBA sum (alpha counts samples) that pt_resolve turns into the images. */
+#define PT_ACCUM_LITERAL 0
+#define PT_ACCUM_LINEAR  1
+int pt_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, const uint32_t *seeds, int mode);
+/* seeds of frames first..first+count-1 under the fixed-seed convention: output
+ * number 16*f of the 32-bit Mersenne twister seeded with base_seed (the reference
+ * draws 16 values per frame from std::random_device and uses the first:
+ * ray_tracer.cpp:293-318). */
+void pt_frame_seeds(uint32_t base_seed, uint32_t first_frame, uint32_t count, uint32_t *out);
+/* frame counter (RayTracer::frame_count) */
+int pt_get_frame_count(pt_context *ctx, uint32_t *frames);
+int pt_reset_accumulation(pt_context *ctx);            /* frame_count = 0, images cleared */
+
+/* linear-sum path: device pointer of the float RGBA sum (width*height*16 bytes) so a
+ * caller can reduce it across GPUs (RCCL) before resolving; pt_resolve writes
+ * pow(sum.rgb / sum.a, 1/2.2) to the output image and the display image. */
+int pt_linear_sum_device_ptr(pt_context *ctx, void **dev_ptr, size_t *bytes);
+int pt_resolve(pt_context *ctx);
+
+/* outputs: `output` RGBA32F (textures_[output_tex_index]) and `output_u` RGBA8
+ * (textures_[output_unorm_tex_index], what CS.cpp:503,511 reads) */
+int pt_download_output(pt_context *ctx, float *rgba32f);
+int pt_download_display(pt_context *ctx, uint8_t *rgba8);
+int pt_output_device_ptr(pt_context *ctx, void **dev_rgba32f, void **dev_rgba8);
+
+/* ---- options & counters --------------------------------------------------------- */
+/* traversal stack entries per path: 15 = the reference (paths silently drop
+ * subtrees beyond it, ray_tracing.hlsl:235-238); larger values are NON-PARITY
+ * for trees deeper than 13 levels.  Allowed: 15 or 32 or 64. */
+int pt_set_stack_size(pt_context *ctx, int entries);
+
+typedef struct pt_counters {
+    uint64_t paths;        /* pixel-frames traced                        */
+    uint64_t rays;         /* intersect() calls = BVH traversals         */
+    uint64_t node_visits;  /* stack pops (only when counting is enabled) */
+    uint64_t box_tests;
+    uint64_t tri_tests;
+} pt_counters;
+/* detailed counting (node_visits/box_tests/tri_tests) uses an instrumented
+ * kernel; paths and rays are always counted */
+int pt_set_detailed_counters(pt_context *ctx, int enabled);
+int pt_get_counters(pt_context *ctx, pt_counters *out);   /* synchronises */
+int pt_reset_counters(pt_context *ctx);
+
+/* single closest-hit queries through the traversal kernel, for tests:
+ * rays = n_rays x {origin.xyz, t_min, direction.xyz, t_max}; results per ray:
+ * hit (0/1), primitive, t, barycentrics (u, v, 1-u-v) */
+typedef struct pt_hit {
+    int32_t hit;
+    int32_t primitive;
+    float   t;
+    float   bary[3];
+} pt_hit;
+int pt_intersect(pt_context *ctx, const float *rays8, int n_rays, pt_hit *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTAMD_H */

@@ -1,0 +1,560 @@
+// C ABI of libptamd (include/ptamd.h): context, uploads, build, trace, downloads.
+// Host-side only; the kernels live in build_kernels.hip / trace_kernels.hip.
+#include "pt_internal.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+static std::string g_create_error;
+
+static int bit_length_u(unsigned v) { return v ? 32 - __builtin_clz(v) : 0; }
+
+template <typename T>
+static int dev_alloc(pt_context *ctx, T **p, size_t count)
+{
+    *p = nullptr;
+    PT_HIP(ctx, hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T)));
+    return PT_OK;
+}
+template <typename T>
+static void dev_free(T *&p)
+{
+    if (p) (void)hipFree((void *)p);
+    p = nullptr;
+}
+
+static void free_build(pt_context *ctx)
+{
+    dev_free(ctx->d_boxes);
+    dev_free(ctx->d_keys[0]); dev_free(ctx->d_keys[1]);
+    dev_free(ctx->d_vals[0]); dev_free(ctx->d_vals[1]);
+    dev_free(ctx->d_morton);
+    dev_free(ctx->d_block_hist);
+    dev_free(ctx->d_tree);
+    dev_free(ctx->d_wide);
+    dev_free(ctx->d_chunk);
+    dev_free(ctx->d_tri);
+    dev_free(ctx->d_shade);
+    ctx->capacity = 0;
+    ctx->built = false;
+}
+
+static void free_images(pt_context *ctx)
+{
+    dev_free(ctx->d_diffuse); dev_free(ctx->d_normal); dev_free(ctx->d_world);
+    dev_free(ctx->d_output); dev_free(ctx->d_display); dev_free(ctx->d_linear);
+    ctx->W = ctx->H = 0;
+    ctx->have_gbuffer = false;
+}
+
+static int set_device(pt_context *ctx)
+{
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    return PT_OK;
+}
+
+extern "C" {
+
+const char *pt_version(void) { return "ptamd 0.1 (gfx950)"; }
+
+int pt_create(int device_ordinal, pt_context **out)
+{
+    if (!out) { g_create_error = "pt_create: out is NULL"; return PT_ERR_INVALID; }
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_create_error = std::string("pt_create: no HIP device (") + hipGetErrorString(e) + ")";
+        return PT_ERR_NO_DEVICE;
+    }
+    if (device_ordinal < 0 || device_ordinal >= count) {
+        g_create_error = "pt_create: device ordinal out of range";
+        return PT_ERR_INVALID;
+    }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_ordinal);
+    if (e != hipSuccess) { g_create_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e); return PT_ERR_HIP; }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("pt_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return PT_ERR_NO_DEVICE;
+    }
+    pt_context *ctx = new pt_context();
+    ctx->device = device_ordinal;
+    int rc = set_device(ctx);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_cb, 1);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_bbox_enc, 16);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_root, 8);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_digit_total, 8 * 256);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_counters, 1);
+    if (!rc) { hipError_t e2 = hipMemset(ctx->d_counters, 0, sizeof(DevCounters)); if (e2 != hipSuccess) rc = PT_ERR_HIP; }
+    for (int i = 0; !rc && i <= PT_STAGE_COUNT; i++) {
+        hipError_t e2 = hipEventCreate(&ctx->ev[i]);
+        if (e2 != hipSuccess) { ctx->err = std::string("hipEventCreate: ") + hipGetErrorString(e2); rc = PT_ERR_HIP; }
+    }
+    if (rc) { g_create_error = ctx->err; pt_destroy(ctx); return rc; }
+    ctx->have_events = true;
+    *out = ctx;
+    return PT_OK;
+}
+
+void pt_destroy(pt_context *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_build(ctx);
+    free_images(ctx);
+    if (ctx->prims_owned) { void *p = const_cast<pt_PrimitiveRender *>(ctx->d_prims); if (p) (void)hipFree(p); }
+    dev_free(ctx->d_cb); dev_free(ctx->d_bbox_enc); dev_free(ctx->d_root); dev_free(ctx->d_digit_total);
+    dev_free(ctx->d_counters); dev_free(ctx->d_seeds);
+    for (int i = 0; i <= PT_STAGE_COUNT; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    delete ctx;
+}
+
+const char *pt_last_error(const pt_context *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int pt_set_stream(pt_context *ctx, void *hip_stream)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return PT_OK;
+}
+
+int pt_synchronize(pt_context *ctx)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (int rc = set_device(ctx)) return rc;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+// ---------------------------------------------------------------------------
+static int set_primitives(pt_context *ctx, const void *dev, int n, bool owned)
+{
+    if (ctx->prims_owned && ctx->d_prims) (void)hipFree(const_cast<pt_PrimitiveRender *>(ctx->d_prims));
+    ctx->d_prims = reinterpret_cast<const pt_PrimitiveRender *>(dev);
+    ctx->prims_owned = owned;
+    ctx->n = n;
+    ctx->built = false;
+    return PT_OK;
+}
+
+int pt_upload_primitives(pt_context *ctx, const pt_PrimitiveRender *host_prims, int n)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!host_prims || n < 1) PT_FAIL(ctx, PT_ERR_INVALID, "pt_upload_primitives: need n >= 1 primitives");
+    if (n >= (1 << 30)) PT_FAIL(ctx, PT_ERR_UNSUPPORTED, "pt_upload_primitives: n must be below 2^30");
+    if (int rc = set_device(ctx)) return rc;
+    void *d = nullptr;
+    PT_HIP(ctx, hipMalloc(&d, (size_t)n * sizeof(pt_PrimitiveRender)));
+    hipError_t e = hipMemcpyAsync(d, host_prims, (size_t)n * sizeof(pt_PrimitiveRender), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(d); ctx->err = std::string("upload primitives: ") + hipGetErrorString(e); return PT_ERR_HIP; }
+    return set_primitives(ctx, d, n, true);
+}
+
+int pt_upload_primitives_device(pt_context *ctx, const void *dev_prims, int n)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!dev_prims || n < 1) PT_FAIL(ctx, PT_ERR_INVALID, "pt_upload_primitives_device: need n >= 1 primitives");
+    if (n >= (1 << 30)) PT_FAIL(ctx, PT_ERR_UNSUPPORTED, "pt_upload_primitives_device: n must be below 2^30");
+    if ((reinterpret_cast<uintptr_t>(dev_prims) & 15u) != 0)
+        PT_FAIL(ctx, PT_ERR_INVALID, "pt_upload_primitives_device: pointer must be 16-byte aligned");
+    return set_primitives(ctx, dev_prims, n, false);
+}
+
+int pt_set_constants(pt_context *ctx, const pt_CB_Radix *cb)
+{
+    if (!ctx || !cb) return PT_ERR_INVALID;
+    if (int rc = set_device(ctx)) return rc;
+    ctx->cb = *cb;
+    ctx->have_cb = true;
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_cb, &ctx->cb, sizeof(pt_CB_Radix), hipMemcpyHostToDevice, ctx->stream));
+    return PT_OK;
+}
+
+// ---------------------------------------------------------------------------
+static int ensure_build_buffers(pt_context *ctx)
+{
+    const int n = ctx->n;
+    if (ctx->capacity >= n) return PT_OK;
+    free_build(ctx);
+    const size_t nblocks = ((size_t)n + PT_SORT_TILE - 1) / PT_SORT_TILE;
+    const size_t nchunks = ((size_t)n + 1 + PT_REFIT_CHUNK - 1) / PT_REFIT_CHUNK;
+    int rc = dev_alloc(ctx, &ctx->d_boxes, (size_t)n);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_keys[0], (size_t)n);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_keys[1], (size_t)n);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_vals[0], (size_t)n);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_vals[1], (size_t)n);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_morton, (size_t)n);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_block_hist, 256 * nblocks);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_tree, 2 * (size_t)n + 1);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_wide, (size_t)n);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_chunk, nchunks);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_tri, (size_t)n);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_shade, (size_t)n);
+    if (rc) { free_build(ctx); return rc; }
+    ctx->capacity = n;
+    return PT_OK;
+}
+
+int pt_build(pt_context *ctx, unsigned flags)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->d_prims || ctx->n < 1) PT_FAIL(ctx, PT_ERR_INVALID, "pt_build: no primitives uploaded");
+    if (flags & ~(PT_BUILD_MORTON_FULL | PT_BUILD_NO_TREE_EXPORT)) PT_FAIL(ctx, PT_ERR_INVALID, "pt_build: unknown flag");
+    if (int rc = set_device(ctx)) return rc;
+    if (int rc = ensure_build_buffers(ctx)) return rc;
+    ctx->built = false;
+    if (int rc = ptk_build(ctx, flags)) return rc;
+    if (int rc = ptk_root_box(ctx)) return rc;
+    ctx->build_flags = flags;
+    ctx->built = true;
+    return PT_OK;
+}
+
+int pt_build_times(pt_context *ctx, float stage_ms[PT_STAGE_COUNT], float *total_ms, int *sort_passes)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->built) PT_FAIL(ctx, PT_ERR_INVALID, "pt_build_times: nothing built");
+    if (int rc = set_device(ctx)) return rc;
+    PT_HIP(ctx, hipEventSynchronize(ctx->ev[PT_STAGE_COUNT]));
+    float tot = 0;
+    for (int i = 0; i < PT_STAGE_COUNT; i++) {
+        float ms = 0;
+        PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
+        if (stage_ms) stage_ms[i] = ms;
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (sort_passes) *sort_passes = ctx->sort_passes;
+    return PT_OK;
+}
+
+#define PT_NEED_BUILT(ctx, who) do { if (!(ctx)) return PT_ERR_INVALID; \
+    if (!(ctx)->built) PT_FAIL(ctx, PT_ERR_INVALID, who ": call pt_build first"); \
+    if (int rc_ = set_device(ctx)) return rc_; } while (0)
+
+static int d2h(pt_context *ctx, void *dst, const void *src, size_t bytes)
+{
+    PT_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_download_scene_bound(pt_context *ctx, pt_Bound *bb)
+{
+    PT_NEED_BUILT(ctx, "pt_download_scene_bound");
+    if (!bb) return PT_ERR_INVALID;
+    unsigned enc[6];
+    if (int rc = d2h(ctx, enc, ctx->d_bbox_enc, sizeof(enc))) return rc;
+    auto dec = [](unsigned u) { unsigned v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; std::memcpy(&f, &v, 4); return f; };
+    std::memset(bb, 0, sizeof(*bb));
+    for (int k = 0; k < 3; k++) { bb->min.v[k] = dec(enc[k]); bb->max.v[k] = dec(enc[3 + k]); }
+    return PT_OK;
+}
+
+int pt_download_morton(pt_context *ctx, uint64_t *codes)
+{
+    PT_NEED_BUILT(ctx, "pt_download_morton");
+    if (!codes) return PT_ERR_INVALID;
+    return d2h(ctx, codes, ctx->d_morton, (size_t)ctx->n * sizeof(uint64_t));
+}
+
+int pt_download_permutation(pt_context *ctx, int32_t *perm)
+{
+    PT_NEED_BUILT(ctx, "pt_download_permutation");
+    if (!perm) return PT_ERR_INVALID;
+    return d2h(ctx, perm, ctx->d_vals[ctx->sorted_buf], (size_t)ctx->n * sizeof(uint32_t));
+}
+
+int pt_download_sorted_primitives(pt_context *ctx, pt_PrimitiveRayCS *out)
+{
+    PT_NEED_BUILT(ctx, "pt_download_sorted_primitives");
+    if (!out) return PT_ERR_INVALID;
+    pt_PrimitiveRayCS *d = nullptr;
+    if (int rc = dev_alloc(ctx, &d, (size_t)ctx->n)) return rc;
+    int rc = ptk_export_sorted(ctx, d);
+    if (!rc) rc = d2h(ctx, out, d, (size_t)ctx->n * sizeof(pt_PrimitiveRayCS));
+    (void)hipFree(d);
+    return rc;
+}
+
+int pt_download_tree(pt_context *ctx, pt_TreeNode *out)
+{
+    PT_NEED_BUILT(ctx, "pt_download_tree");
+    if (!out) return PT_ERR_INVALID;
+    if (ctx->build_flags & PT_BUILD_NO_TREE_EXPORT) PT_FAIL(ctx, PT_ERR_INVALID, "pt_download_tree: built with PT_BUILD_NO_TREE_EXPORT");
+    return d2h(ctx, out, ctx->d_tree, 2 * (size_t)ctx->n * sizeof(pt_TreeNode));
+}
+
+// ---------------------------------------------------------------------------
+int pt_resize(pt_context *ctx, int width, int height)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (width < 1 || height < 1 || (long long)width * height > (1ll << 28)) PT_FAIL(ctx, PT_ERR_INVALID, "pt_resize: bad size");
+    if (int rc = set_device(ctx)) return rc;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_images(ctx);
+    const size_t npix = (size_t)width * height;
+    int rc = dev_alloc(ctx, &ctx->d_diffuse, npix * 4);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_normal, npix);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_world, npix);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_output, npix);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_display, npix * 4);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_linear, npix);
+    if (rc) { free_images(ctx); return rc; }
+    ctx->W = width;
+    ctx->H = height;
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_diffuse, 0, npix * 4, ctx->stream));
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_normal, 0, npix * 16, ctx->stream));
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_world, 0, npix * 16, ctx->stream));
+    return pt_reset_accumulation(ctx);
+}
+
+int pt_reset_accumulation(pt_context *ctx)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->W) PT_FAIL(ctx, PT_ERR_INVALID, "pt_reset_accumulation: call pt_resize first");
+    if (int rc = set_device(ctx)) return rc;
+    const size_t npix = (size_t)ctx->W * ctx->H;
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_output, 0, npix * 16, ctx->stream));
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_display, 0, npix * 4, ctx->stream));
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_linear, 0, npix * 16, ctx->stream));
+    ctx->frame_count = 0;
+    return PT_OK;
+}
+
+int pt_upload_gbuffer(pt_context *ctx, const uint8_t *diffuse, const float *normal, const float *world)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->W) PT_FAIL(ctx, PT_ERR_INVALID, "pt_upload_gbuffer: call pt_resize first");
+    if (!diffuse || !normal || !world) return PT_ERR_INVALID;
+    if (int rc = set_device(ctx)) return rc;
+    const size_t npix = (size_t)ctx->W * ctx->H;
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_diffuse, diffuse, npix * 4, hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_normal, normal, npix * 16, hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_world, world, npix * 16, hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_gbuffer = true;
+    return PT_OK;
+}
+
+int pt_download_gbuffer(pt_context *ctx, uint8_t *diffuse, float *normal, float *world)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->have_gbuffer) PT_FAIL(ctx, PT_ERR_INVALID, "pt_download_gbuffer: no G-buffer yet");
+    if (int rc = set_device(ctx)) return rc;
+    const size_t npix = (size_t)ctx->W * ctx->H;
+    if (diffuse) PT_HIP(ctx, hipMemcpyAsync(diffuse, ctx->d_diffuse, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (normal) PT_HIP(ctx, hipMemcpyAsync(normal, ctx->d_normal, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (world) PT_HIP(ctx, hipMemcpyAsync(world, ctx->d_world, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+// Bytes the colour render target holds for a material colour.  The reference
+// renders Kd into an sRGB back buffer and copies the raw bytes into a UNORM
+// texture (CS.cpp:302,357-359,373), so its shader samples the sRGB-ENCODED
+// value; srgb_quirk = 0 stores plain UNORM8.
+void pt_albedo_bytes(const float kd[3], int srgb_quirk, uint8_t out_rgb[3])
+{
+    for (int k = 0; k < 3; k++) {
+        double c = kd[k];
+        if (!(c == c) || c < 0.0) c = 0.0;
+        if (c > 1.0) c = 1.0;
+        if (srgb_quirk) c = (c <= 0.0031308) ? 12.92 * c : 1.055 * std::pow(c, 1.0 / 2.4) - 0.055;
+        out_rgb[k] = (uint8_t)(int)(c * 255.0 + 0.5);
+    }
+}
+
+int pt_primary_hits(pt_context *ctx, const pt_camera *cam, const uint8_t *albedo_rgba8)
+{
+    PT_NEED_BUILT(ctx, "pt_primary_hits");
+    if (!cam || !albedo_rgba8) return PT_ERR_INVALID;
+    if (!ctx->W) PT_FAIL(ctx, PT_ERR_INVALID, "pt_primary_hits: call pt_resize first");
+    uint8_t *d_alb = nullptr;
+    if (int rc = dev_alloc(ctx, &d_alb, 64)) return rc;
+    hipError_t e = hipMemcpyAsync(d_alb, albedo_rgba8, 64, hipMemcpyHostToDevice, ctx->stream);
+    int rc = PT_OK;
+    if (e != hipSuccess) { ctx->err = std::string("albedo upload: ") + hipGetErrorString(e); rc = PT_ERR_HIP; }
+    if (!rc) rc = ptk_primary(ctx, cam, d_alb);
+    if (!rc) { e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) { ctx->err = hipGetErrorString(e); rc = PT_ERR_HIP; } }
+    (void)hipFree(d_alb);
+    if (!rc) ctx->have_gbuffer = true;
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
+// MT19937 raw outputs (what std::mt19937 specifies)
+void pt_frame_seeds(uint32_t base_seed, uint32_t first_frame, uint32_t count, uint32_t *out)
+{
+    uint32_t mt[624];
+    mt[0] = base_seed;
+    for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    int idx = 624;
+    auto next = [&]() -> uint32_t {
+        if (idx >= 624) {
+            for (int i = 0; i < 624; i++) {
+                uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+                mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        return y;
+    };
+    for (uint64_t i = 0, skip = (uint64_t)first_frame * 16u; i < skip; i++) (void)next();
+    for (uint32_t f = 0; f < count; f++) {
+        out[f] = next();
+        for (int k = 1; k < 16; k++) (void)next();
+    }
+}
+
+static int check_trace_ready(pt_context *ctx, const char *who)
+{
+    if (!ctx->built) PT_FAIL(ctx, PT_ERR_INVALID, std::string(who) + ": call pt_build first");
+    if (!ctx->have_cb) PT_FAIL(ctx, PT_ERR_INVALID, std::string(who) + ": call pt_set_constants first");
+    if (ctx->cb.node_count != ctx->n) PT_FAIL(ctx, PT_ERR_INVALID, std::string(who) + ": CB_Radix.node_count differs from the primitive count");
+    if (!ctx->W) PT_FAIL(ctx, PT_ERR_INVALID, std::string(who) + ": call pt_resize first");
+    if (!ctx->have_gbuffer) PT_FAIL(ctx, PT_ERR_INVALID, std::string(who) + ": no G-buffer (pt_upload_gbuffer / pt_primary_hits)");
+    // The reference's 15-entry stack silently drops subtrees of trees deeper than
+    // 13 levels; this library never drops, so such scenes need the explicit opt-in.
+    if (ctx->stack_entries == 15 && bit_length_u((unsigned)ctx->n) > 14)
+        PT_FAIL(ctx, PT_ERR_UNSUPPORTED, std::string(who) + ": tree deeper than the 15-entry reference stack; pt_set_stack_size(ctx, 32)");
+    return PT_OK;
+}
+
+int pt_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, const uint32_t *seeds, int mode)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (int rc = check_trace_ready(ctx, "pt_trace_frames")) return rc;
+    if (!seeds || count < 1) PT_FAIL(ctx, PT_ERR_INVALID, "pt_trace_frames: need count >= 1 seeds");
+    if (mode != PT_ACCUM_LITERAL && mode != PT_ACCUM_LINEAR) PT_FAIL(ctx, PT_ERR_INVALID, "pt_trace_frames: bad mode");
+    if (int rc = set_device(ctx)) return rc;
+    if (ctx->seeds_cap < count) {
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        dev_free(ctx->d_seeds);
+        ctx->seeds_cap = 0;
+        if (int rc = dev_alloc(ctx, &ctx->d_seeds, (size_t)count)) return rc;
+        ctx->seeds_cap = count;
+    }
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // the previous launch may still read h_seeds' old storage
+    ctx->h_seeds.assign(seeds, seeds + count);
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_seeds, ctx->h_seeds.data(), (size_t)count * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = ptk_trace_frames(ctx, first_frame, count, mode)) return rc;
+    ctx->frame_count = first_frame + count;
+    return PT_OK;
+}
+
+int pt_trace(pt_context *ctx, uint32_t framecount, uint32_t seed)
+{
+    return pt_trace_frames(ctx, framecount, 1, &seed, PT_ACCUM_LITERAL);
+}
+
+int pt_get_frame_count(pt_context *ctx, uint32_t *frames)
+{
+    if (!ctx || !frames) return PT_ERR_INVALID;
+    *frames = ctx->frame_count;
+    return PT_OK;
+}
+
+int pt_linear_sum_device_ptr(pt_context *ctx, void **dev_ptr, size_t *bytes)
+{
+    if (!ctx || !dev_ptr) return PT_ERR_INVALID;
+    if (!ctx->W) PT_FAIL(ctx, PT_ERR_INVALID, "pt_linear_sum_device_ptr: call pt_resize first");
+    *dev_ptr = ctx->d_linear;
+    if (bytes) *bytes = (size_t)ctx->W * ctx->H * 16;
+    return PT_OK;
+}
+
+int pt_resolve(pt_context *ctx)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->W) PT_FAIL(ctx, PT_ERR_INVALID, "pt_resolve: call pt_resize first");
+    if (int rc = set_device(ctx)) return rc;
+    return ptk_resolve(ctx);
+}
+
+int pt_download_output(pt_context *ctx, float *rgba32f)
+{
+    if (!ctx || !rgba32f) return PT_ERR_INVALID;
+    if (!ctx->W) PT_FAIL(ctx, PT_ERR_INVALID, "pt_download_output: call pt_resize first");
+    if (int rc = set_device(ctx)) return rc;
+    return d2h(ctx, rgba32f, ctx->d_output, (size_t)ctx->W * ctx->H * 16);
+}
+
+int pt_download_display(pt_context *ctx, uint8_t *rgba8)
+{
+    if (!ctx || !rgba8) return PT_ERR_INVALID;
+    if (!ctx->W) PT_FAIL(ctx, PT_ERR_INVALID, "pt_download_display: call pt_resize first");
+    if (int rc = set_device(ctx)) return rc;
+    return d2h(ctx, rgba8, ctx->d_display, (size_t)ctx->W * ctx->H * 4);
+}
+
+int pt_output_device_ptr(pt_context *ctx, void **dev_rgba32f, void **dev_rgba8)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->W) PT_FAIL(ctx, PT_ERR_INVALID, "pt_output_device_ptr: call pt_resize first");
+    if (dev_rgba32f) *dev_rgba32f = ctx->d_output;
+    if (dev_rgba8) *dev_rgba8 = ctx->d_display;
+    return PT_OK;
+}
+
+// ---------------------------------------------------------------------------
+int pt_set_stack_size(pt_context *ctx, int entries)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (entries != 0 && entries != 15 && entries != 32) PT_FAIL(ctx, PT_ERR_INVALID, "pt_set_stack_size: 0 (automatic), 15 or 32");
+    ctx->stack_entries = entries;
+    return PT_OK;
+}
+
+int pt_set_detailed_counters(pt_context *ctx, int enabled)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    ctx->detailed = enabled != 0;
+    return PT_OK;
+}
+
+int pt_get_counters(pt_context *ctx, pt_counters *out)
+{
+    if (!ctx || !out) return PT_ERR_INVALID;
+    if (int rc = set_device(ctx)) return rc;
+    DevCounters h;
+    if (int rc = d2h(ctx, &h, ctx->d_counters, sizeof(h))) return rc;
+    out->paths = h.paths; out->rays = h.rays; out->node_visits = h.node_visits;
+    out->box_tests = h.box_tests; out->tri_tests = h.tri_tests;
+    return PT_OK;
+}
+
+int pt_reset_counters(pt_context *ctx)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (int rc = set_device(ctx)) return rc;
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DevCounters), ctx->stream));
+    return PT_OK;
+}
+
+int pt_intersect(pt_context *ctx, const float *rays8, int n_rays, pt_hit *out)
+{
+    PT_NEED_BUILT(ctx, "pt_intersect");
+    if (!rays8 || !out || n_rays < 1) return PT_ERR_INVALID;
+    float *d_rays = nullptr;
+    pt_hit *d_out = nullptr;
+    int rc = dev_alloc(ctx, &d_rays, (size_t)n_rays * 8);
+    if (!rc) rc = dev_alloc(ctx, &d_out, (size_t)n_rays);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(d_rays, rays8, (size_t)n_rays * 32, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { ctx->err = hipGetErrorString(e); rc = PT_ERR_HIP; }
+    }
+    if (!rc) rc = ptk_intersect(ctx, d_rays, n_rays, d_out);
+    if (!rc) rc = d2h(ctx, out, d_out, (size_t)n_rays * sizeof(pt_hit));
+    if (d_rays) (void)hipFree(d_rays);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
+}  // extern "C"

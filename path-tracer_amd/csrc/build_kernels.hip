@@ -1,0 +1,560 @@
+// Acceleration-structure build on gfx950: per-triangle boxes + scene box,
+// Morton codes, stable LSD radix sort, binary-radix-tree links, bottom-up
+// boxes, triangle records for traversal.
+//
+// Follows (reference): ray_tracer.cpp:41-66 (boxes, scene box, codes, sort,
+// strip), structs.hpp:81-116 (genMortonCode, mergeBound), radix_build_cs.hlsl
+// (tree links), bvh_build_cs.hlsl (leaf init + box merge).
+//
+// All stages are HBM-streaming integer / min-max work: no matrix cores.  Wave
+// size is 64 throughout.  Compile with -ffp-contract=off (Morton arithmetic
+// must not be fused).
+#include "pt_internal.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned enc_f(float f)
+{   // order-preserving float -> uint (for atomicMin/atomicMax)
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f(unsigned u)
+{
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// stage 1: per-triangle boxes + scene box          (ray_tracer.cpp:41-54)
+// A workgroup stages 256 consecutive 80-byte records through LDS with 16-byte
+// coalesced loads, then each lane reads its own triangle.
+// ---------------------------------------------------------------------------
+constexpr int PRIM_DW = 20;   // dwords per PrimitiveRender
+
+__global__ __launch_bounds__(256) void k_bounds(const uint4 *__restrict__ prims16, int n,
+                                                BoxRec *__restrict__ boxes, unsigned *__restrict__ bbox_enc)
+{
+    __shared__ uint4 stage[256 * PRIM_DW / 4];      // 20480 B
+    __shared__ float red[6][4];
+    const int t = threadIdx.x;
+    const long long first = (long long)blockIdx.x * 256;
+    const int cnt = (int)min((long long)256, (long long)n - first);
+    const int n16 = cnt * (PRIM_DW / 4);
+    const uint4 *src = prims16 + first * (PRIM_DW / 4);
+    for (int i = t; i < n16; i += 256) stage[i] = src[i];
+    __syncthreads();
+
+    float mn[3], mx[3];
+    if (t < cnt) {
+        const float *p = reinterpret_cast<const float *>(stage) + t * PRIM_DW;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float x = p[k], y = p[6 + k], z = p[12 + k];
+            // math3d.h:13-23: max(x, max(y, z)) / min(x, min(y, z))
+            float yz_max = (y > z) ? y : z, yz_min = (y < z) ? y : z;
+            mx[k] = (x > yz_max) ? x : yz_max;
+            mn[k] = (x < yz_min) ? x : yz_min;
+        }
+        BoxRec b;
+        b.mn[0] = mn[0]; b.mn[1] = mn[1]; b.mn[2] = mn[2]; b.pad = 0.0f;
+        b.mx[0] = mx[0]; b.mx[1] = mx[1]; b.mx[2] = mx[2]; b.index = (int32_t)(first + t);
+        float4 *dst = reinterpret_cast<float4 *>(&boxes[first + t]);
+        dst[0] = make_float4(b.mn[0], b.mn[1], b.mn[2], 0.0f);
+        dst[1] = make_float4(b.mx[0], b.mx[1], b.mx[2], __int_as_float(b.index));
+    } else {
+        const float inf = __uint_as_float(0x7f800000u);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { mn[k] = inf; mx[k] = -inf; }
+    }
+    const int wave = t >> 6, lane = t & 63;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float a = wave_min(mn[k]), b = wave_max(mx[k]);
+        if (lane == 0) { red[k][wave] = a; red[3 + k][wave] = b; }
+    }
+    __syncthreads();
+    if (t < 3) {
+        float a = fminf(fminf(red[t][0], red[t][1]), fminf(red[t][2], red[t][3]));
+        atomicMin(&bbox_enc[t], enc_f(a));
+    } else if (t < 6) {
+        float b = fmaxf(fmaxf(red[t][0], red[t][1]), fmaxf(red[t][2], red[t][3]));
+        atomicMax(&bbox_enc[t], enc_f(b));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// stage 2: Morton codes                                 (structs.hpp:81-105)
+// Strict IEEE evaluation of ((mid - min) / (max - min)) * L per axis, then bit
+// interleave with x in the highest of each triple.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t spread3(uint64_t v)
+{   // bit i of v (i < 21) -> bit 3*i
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x1f00000000ffffull;
+    v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_morton(const BoxRec *__restrict__ boxes, int n,
+                                                const unsigned *__restrict__ bbox_enc, float cells,
+                                                uint64_t *__restrict__ codes)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 *src = reinterpret_cast<const float4 *>(&boxes[i]);
+    float4 lo = src[0], hi = src[1];
+    float min_x = dec_f(bbox_enc[0]), min_y = dec_f(bbox_enc[1]), min_z = dec_f(bbox_enc[2]);
+    float max_x = dec_f(bbox_enc[3]), max_y = dec_f(bbox_enc[4]), max_z = dec_f(bbox_enc[5]);
+    float midx = (lo.x + hi.x) / 2;
+    float midy = (lo.y + hi.y) / 2;
+    float midz = (lo.z + hi.z) / 2;
+    uint64_t a = (uint64_t)(((midx - min_x) / (max_x - min_x)) * cells);
+    uint64_t b = (uint64_t)(((midy - min_y) / (max_y - min_y)) * cells);
+    uint64_t c = (uint64_t)(((midz - min_z) / (max_z - min_z)) * cells);
+    codes[i] = (spread3(a) << 2) | (spread3(b) << 1) | spread3(c);
+}
+
+// ---------------------------------------------------------------------------
+// stage 3: stable LSD radix sort, 8-bit digits, (64-bit key, 32-bit index)
+//   per pass: k_sort_hist (per-workgroup digit counts, LDS histogram)
+//             k_sort_scan (one workgroup per digit scans its row of counts)
+//             k_sort_scatter (wave64 ballot match -> stable ranks, LDS-staged
+//                             reorder, coalesced runs out)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(PT_SORT_THREADS) void k_sort_hist(const uint64_t *__restrict__ keys, int n, int shift,
+                                                               uint32_t *__restrict__ block_hist,
+                                                               uint32_t *__restrict__ digit_total, int nblocks)
+{
+    __shared__ uint32_t h[256];
+    const int t = threadIdx.x;
+    h[t] = 0;
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * PT_SORT_TILE;
+#pragma unroll 4
+    for (int i = t; i < PT_SORT_TILE; i += PT_SORT_THREADS) {
+        long long g = base + i;
+        if (g < n) atomicAdd(&h[(unsigned)(keys[g] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    uint32_t c = h[t];
+    block_hist[(size_t)t * nblocks + blockIdx.x] = c;
+    if (c) atomicAdd(&digit_total[t], c);
+}
+
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t x, uint32_t *sh /*[5]*/, uint32_t *total)
+{   // exclusive scan over the 256 threads of the workgroup
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t v = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    __syncthreads();                 // protects sh[] against the previous use
+    if (lane == 63) sh[wave] = v;
+    __syncthreads();
+    uint32_t w0 = sh[0], w1 = sh[1], w2 = sh[2], w3 = sh[3];
+    uint32_t off = (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
+    *total = w0 + w1 + w2 + w3;
+    return off + v - x;
+}
+
+__global__ __launch_bounds__(256) void k_sort_scan(uint32_t *__restrict__ block_hist,
+                                                   const uint32_t *__restrict__ digit_total, int nblocks)
+{
+    __shared__ uint32_t sh[5];
+    const int d = blockIdx.x, t = threadIdx.x;
+    uint32_t tot;
+    uint32_t mine = (t < d) ? digit_total[t] : 0u;
+    (void)block_excl_scan_256(mine, sh, &tot);      // tot = sum of totals of lower digits
+    uint32_t carry = tot;
+    uint32_t *row = block_hist + (size_t)d * nblocks;
+    for (int c = 0; c < nblocks; c += 256) {
+        int i = c + t;
+        uint32_t x = (i < nblocks) ? row[i] : 0u;
+        uint32_t sum;
+        uint32_t ex = block_excl_scan_256(x, sh, &sum);
+        if (i < nblocks) row[i] = carry + ex;
+        carry += sum;
+    }
+}
+
+template <bool IOTA>
+__global__ __launch_bounds__(PT_SORT_THREADS) void k_sort_scatter(
+    const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+    uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int n, int shift,
+    const uint32_t *__restrict__ block_off, int nblocks)
+{
+    __shared__ uint64_t skeys[PT_SORT_TILE];            // 32 KB
+    __shared__ uint32_t svals[PT_SORT_TILE];            // 16 KB
+    __shared__ uint32_t wave_hist[4][256];              //  4 KB
+    __shared__ uint32_t digit_base[256];
+    __shared__ uint32_t sh[5];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = t; i < 4 * 256; i += PT_SORT_THREADS) (&wave_hist[0][0])[i] = 0;
+    __syncthreads();
+
+    const long long tile_base = (long long)blockIdx.x * PT_SORT_TILE;
+    const long long wave_base = tile_base + (long long)wave * (PT_SORT_ITEMS * 64);
+    const int tile_cnt = (int)min((long long)PT_SORT_TILE, (long long)n - tile_base);
+
+    uint64_t key[PT_SORT_ITEMS];
+    uint32_t val[PT_SORT_ITEMS];
+    uint32_t rank[PT_SORT_ITEMS];
+#pragma unroll
+    for (int r = 0; r < PT_SORT_ITEMS; r++) {
+        long long g = wave_base + r * 64 + lane;
+        bool valid = g < n;
+        key[r] = valid ? keys_in[g] : ~0ull;
+        val[r] = IOTA ? (uint32_t)g : (valid ? vals_in[g] : 0u);
+    }
+    volatile uint32_t *wh = wave_hist[wave];
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < PT_SORT_ITEMS; r++) {
+        // out-of-range slots take digit 255 and, being last in input order, end
+        // up behind every real key of the tile; they are never written out
+        uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+        uint64_t peers = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            bool bit = (d >> b) & 1u;
+            uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        uint32_t lower = __popcll(peers & lt_mask);
+        uint32_t prev = wh[d];
+        rank[r] = prev + lower;
+        __builtin_amdgcn_wave_barrier();
+        if (lower == 0) wh[d] = prev + __popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {   // per digit: exclusive prefix over the four waves, then over the digits
+        uint32_t c0 = wave_hist[0][t], c1 = wave_hist[1][t], c2 = wave_hist[2][t], c3 = wave_hist[3][t];
+        uint32_t tot = c0 + c1 + c2 + c3, dummy;
+        wave_hist[0][t] = 0; wave_hist[1][t] = c0; wave_hist[2][t] = c0 + c1; wave_hist[3][t] = c0 + c1 + c2;
+        digit_base[t] = block_excl_scan_256(tot, sh, &dummy);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PT_SORT_ITEMS; r++) {
+        uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+        uint32_t p = digit_base[d] + wave_hist[wave][d] + rank[r];
+        skeys[p] = key[r];
+        svals[p] = val[r];
+    }
+    __syncthreads();
+    for (int i = t; i < tile_cnt; i += PT_SORT_THREADS) {
+        uint64_t k = skeys[i];
+        uint32_t d = (uint32_t)(k >> shift) & 255u;
+        uint32_t dst = block_off[(size_t)d * nblocks + blockIdx.x] + ((uint32_t)i - digit_base[d]);
+        keys_out[dst] = k;
+        vals_out[dst] = svals[i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// stage 4: binary radix tree links                    (radix_build_cs.hlsl)
+// Keyed on the leaf index over the range [0, n]: delta(i, j) = clz(i ^ j), or -1
+// outside the range.  One lane per internal node; writes left/right of the
+// node and parent of both children.  Node 2n lies outside the reference's
+// buffer: writes to it are dropped.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int lcp(int i, int j, int len)
+{
+    return (0 <= j && j < len) ? __clz(i ^ j) : -1;
+}
+
+__global__ __launch_bounds__(256) void k_radix_tree(int n, pt_TreeNode *__restrict__ tree)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int len = n + 1;
+    const int d = (lcp(i, i + 1, len) - lcp(i, i - 1, len) > 0) ? 1 : -1;
+    const int sig_min = lcp(i, i - d, len);
+    int lmax = 2;
+    while (lcp(i, i + lmax * d, len) > sig_min) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (lcp(i, i + (l + t) * d, len) > sig_min) l += t;
+    const int j = i + l * d;
+    const int sig_node = lcp(i, j, len);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (lcp(i, i + (s + t) * d, len) > sig_node) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + min(d, 0);
+    const int left = (min(i, j) == gamma) ? gamma + n : gamma;
+    const int right = (max(i, j) == gamma + 1) ? n + gamma + 1 : gamma + 1;
+    tree[i].left = left;
+    tree[i].right = right;
+    if (i == 0) tree[0].parent = 0;
+    tree[left].parent = i;
+    if (right < 2 * n) tree[right].parent = i;
+}
+
+// ---------------------------------------------------------------------------
+// stage 5: leaf init + bottom-up boxes                 (bvh_build_cs.hlsl)
+// The tree over keys 0..n is the binary trie of the key indices, so the node
+// with a given range is known in closed form: at level k (split on bit k-1) the
+// block b covers keys [b*2^k, min((b+1)*2^k - 1, n)] and is a node iff
+// b*2^k + 2^(k-1) <= n; its id is the LAST key of the range when it is a left
+// child (b even and (b+1)*2^k <= n), else the FIRST key.  Levels are processed
+// bottom-up with no inter-workgroup hand-off: levels 1..10 of a 1024-key chunk
+// inside one workgroup through LDS, higher levels one launch per level over the
+// per-chunk boxes.  Key n is the out-of-range leaf: all-zero box, primitive 0.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int node_id(long long b, int k, int n)
+{
+    long long s = b << k;
+    return ((b & 1) == 0 && ((b + 1) << k) <= (long long)n) ? (int)(((b + 1) << k) - 1) : (int)s;
+}
+
+__device__ __forceinline__ void write_wide(WideNode *__restrict__ w, const float *L, const float *R, int left, int right)
+{
+    float4 *dst = reinterpret_cast<float4 *>(w);
+    dst[0] = make_float4(L[0], L[1], L[2], L[3]);
+    dst[1] = make_float4(L[4], L[5], R[0], R[1]);
+    dst[2] = make_float4(R[2], R[3], R[4], R[5]);
+    dst[3] = make_float4(__int_as_float(left), __int_as_float(right), 0.0f, 0.0f);
+}
+
+__device__ __forceinline__ void write_tree_box(pt_TreeNode *__restrict__ node, int index, const float *U)
+{   // fields index, bound, padding (bytes 12..47); left/right/parent belong to k_radix_tree
+    node->index = index;
+    node->bound.min.v[0] = U[0]; node->bound.min.v[1] = U[1]; node->bound.min.v[2] = U[2];
+    node->bound.padding0 = 0.0f;
+    node->bound.max.v[0] = U[3]; node->bound.max.v[1] = U[4]; node->bound.max.v[2] = U[5];
+    node->padding = 0;
+}
+
+__global__ __launch_bounds__(256) void k_refit_low(const uint32_t *__restrict__ perm, const BoxRec *__restrict__ boxes,
+                                                   int n, pt_TreeNode *__restrict__ tree, WideNode *__restrict__ wide,
+                                                   ChunkBox *__restrict__ chunk)
+{
+    __shared__ float sb[6][PT_REFIT_CHUNK];          // 24 KB: min.xyz, max.xyz per key slot
+    __shared__ int sprim[PT_REFIT_CHUNK];            //  4 KB
+    const int t = threadIdx.x;
+    const long long base = (long long)blockIdx.x * PT_REFIT_CHUNK;
+    for (int j = t; j < PT_REFIT_CHUNK; j += 256) {
+        long long key = base + j;
+        float b[6] = {0, 0, 0, 0, 0, 0};
+        int p = 0;
+        if (key < n) {
+            p = (int)perm[key];
+            const float4 *src = reinterpret_cast<const float4 *>(&boxes[p]);
+            float4 lo = src[0], hi = src[1];
+            b[0] = lo.x; b[1] = lo.y; b[2] = lo.z; b[3] = hi.x; b[4] = hi.y; b[5] = hi.z;
+            if (tree) {
+                pt_TreeNode *leaf = &tree[(long long)n + key];
+                leaf->left = 0;
+                leaf->right = 0;
+                write_tree_box(leaf, p, b);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) sb[c][j] = b[c];
+        sprim[j] = p;
+    }
+    __syncthreads();
+    for (int k = 1; k <= PT_REFIT_CHUNK_LOG2; k++) {
+        const int nb = PT_REFIT_CHUNK >> k, half = 1 << (k - 1);
+        for (int bl = t; bl < nb; bl += 256) {
+            const int ls = bl << k;
+            const long long s = base + ls;
+            if (s + half <= n) {
+                const int rs = ls + half;
+                float L[6], R[6], U[6];
+#pragma unroll
+                for (int c = 0; c < 6; c++) { L[c] = sb[c][ls]; R[c] = sb[c][rs]; }
+#pragma unroll
+                for (int c = 0; c < 3; c++) { U[c] = fminf(L[c], R[c]); U[3 + c] = fmaxf(L[3 + c], R[3 + c]); }
+                const long long b = s >> k;
+                const int id = node_id(b, k, n);
+                const long long gamma = s + half - 1;
+                const long long e = min(s + (1ll << k) - 1, (long long)n);
+                const int left = (k == 1) ? ~sprim[ls] : (int)gamma;
+                const int right = (gamma + 1 == e) ? ~sprim[rs] : (int)(gamma + 1);
+                write_wide(&wide[id], L, R, left, right);
+                if (tree) write_tree_box(&tree[id], 0, U);
+#pragma unroll
+                for (int c = 0; c < 6; c++) sb[c][ls] = U[c];
+            }
+        }
+        __syncthreads();
+    }
+    if (t < 6) (&chunk[blockIdx.x].mn[0])[t] = sb[t][0];
+}
+
+__global__ __launch_bounds__(256) void k_refit_level(int k, int n, long long nblocks_level,
+                                                     pt_TreeNode *__restrict__ tree, WideNode *__restrict__ wide,
+                                                     ChunkBox *__restrict__ chunk)
+{
+    const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblocks_level) return;
+    const long long s = b << k, half = 1ll << (k - 1);
+    if (s + half > n) return;
+    const long long gamma = s + half - 1;
+    const long long e = min(s + (1ll << k) - 1, (long long)n);
+    ChunkBox *cl = &chunk[s >> PT_REFIT_CHUNK_LOG2];
+    const ChunkBox *cr = &chunk[(gamma + 1) >> PT_REFIT_CHUNK_LOG2];
+    float L[6], R[6], U[6];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { L[c] = cl->mn[c]; L[3 + c] = cl->mx[c]; R[c] = cr->mn[c]; R[3 + c] = cr->mx[c]; }
+#pragma unroll
+    for (int c = 0; c < 3; c++) { U[c] = fminf(L[c], R[c]); U[3 + c] = fmaxf(L[3 + c], R[3 + c]); }
+    const int id = node_id(b, k, n);
+    // above chunk level a single-key right range can only be key n itself
+    const int right = (gamma + 1 == e) ? ~0 : (int)(gamma + 1);
+    write_wide(&wide[id], L, R, (int)gamma, right);
+    if (tree) write_tree_box(&tree[id], 0, U);
+#pragma unroll
+    for (int c = 0; c < 3; c++) { cl->mn[c] = U[c]; cl->mx[c] = U[3 + c]; }
+}
+
+// ---------------------------------------------------------------------------
+// triangle records for traversal / shading
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_tris(const uint4 *__restrict__ prims16, int n,
+                                                   TriIsect *__restrict__ tri, TriShade *__restrict__ shade)
+{
+    __shared__ uint4 stage[256 * PRIM_DW / 4];
+    const int t = threadIdx.x;
+    const long long first = (long long)blockIdx.x * 256;
+    const int cnt = (int)min((long long)256, (long long)n - first);
+    const int n16 = cnt * (PRIM_DW / 4);
+    const uint4 *src = prims16 + first * (PRIM_DW / 4);
+    for (int i = t; i < n16; i += 256) stage[i] = src[i];
+    __syncthreads();
+    if (t >= cnt) return;
+    const float *p = reinterpret_cast<const float *>(stage) + t * PRIM_DW;
+    const int matid = reinterpret_cast<const int *>(p)[18];
+    float a[3], e1[3], e2[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { a[k] = p[k]; e1[k] = p[6 + k] - p[k]; e2[k] = p[12 + k] - p[k]; }
+    float4 *ti = reinterpret_cast<float4 *>(&tri[first + t]);
+    ti[0] = make_float4(a[0], a[1], a[2], __int_as_float(matid));
+    ti[1] = make_float4(e1[0], e1[1], e1[2], 0.0f);
+    ti[2] = make_float4(e2[0], e2[1], e2[2], 0.0f);
+    float4 *ts = reinterpret_cast<float4 *>(&shade[first + t]);
+    ts[0] = make_float4(p[3], p[4], p[5], __int_as_float(matid));
+    ts[1] = make_float4(p[9], p[10], p[11], 0.0f);
+    ts[2] = make_float4(p[15], p[16], p[17], 0.0f);
+}
+
+// sorted {box, index} records in the reference's ray_cs_primitives layout
+__global__ __launch_bounds__(256) void k_export_sorted(const uint32_t *__restrict__ perm, const BoxRec *__restrict__ boxes,
+                                                       int n, pt_PrimitiveRayCS *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 *src = reinterpret_cast<const float4 *>(&boxes[perm[i]]);
+    float4 *dst = reinterpret_cast<float4 *>(&out[i]);
+    dst[0] = src[0];
+    dst[1] = src[1];
+}
+
+inline int bit_length(unsigned v) { return v ? 32 - __builtin_clz(v) : 0; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// host-side sequencing
+// ---------------------------------------------------------------------------
+int ptk_build(pt_context *ctx, unsigned flags)
+{
+    const int n = ctx->n;
+    hipStream_t st = ctx->stream;
+    const bool want_tree = !(flags & PT_BUILD_NO_TREE_EXPORT);
+    const int grid_n = (n + 255) / 256;
+    const uint4 *prims16 = reinterpret_cast<const uint4 *>(ctx->d_prims);
+
+    // scene-box accumulators: +inf encodings for the minima, -inf for the maxima
+    // (h_bbox_init: enc(+inf) = 0xff800000 three times, enc(-inf) = 0x007fffff three times)
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_bbox_enc, ctx->h_bbox_init, sizeof(ctx->h_bbox_init), hipMemcpyHostToDevice, st));
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_digit_total, 0, 8 * 256 * sizeof(uint32_t), st));
+    if (want_tree) PT_HIP(ctx, hipMemsetAsync(&ctx->d_tree[2 * (size_t)n], 0, sizeof(pt_TreeNode), st));
+
+    PT_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    hipLaunchKernelGGL(k_bounds, dim3(grid_n), dim3(256), 0, st, prims16, n, ctx->d_boxes, ctx->d_bbox_enc);
+    PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_BOUNDS + 1], st));
+
+    const bool full = (flags & PT_BUILD_MORTON_FULL) != 0;
+    const float cells = full ? 2097151.0f : (float)PT_MORTON_CODE_LENGTH_EACH;
+    hipLaunchKernelGGL(k_morton, dim3(grid_n), dim3(256), 0, st, ctx->d_boxes, n, ctx->d_bbox_enc, cells, ctx->d_morton);
+    PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_MORTON + 1], st));
+
+    // The reference quantises each axis to 0..21 (5 bits), so its codes occupy
+    // 15 bits: two 8-bit passes sort them completely.  Full-resolution codes
+    // have 63 bits: eight passes.
+    const int passes = full ? 8 : 2;
+    const int nblocks = (n + PT_SORT_TILE - 1) / PT_SORT_TILE;
+    const uint64_t *kin = ctx->d_morton;
+    const uint32_t *vin = nullptr;
+    int out = 0;
+    for (int p = 0; p < passes; p++) {
+        const int shift = 8 * p;
+        uint32_t *dtot = ctx->d_digit_total + 256 * p;
+        hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, n, shift, ctx->d_block_hist, dtot, nblocks);
+        hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, st, ctx->d_block_hist, dtot, nblocks);
+        if (p == 0)
+            hipLaunchKernelGGL(k_sort_scatter<true>, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, vin,
+                               ctx->d_keys[out], ctx->d_vals[out], n, shift, ctx->d_block_hist, nblocks);
+        else
+            hipLaunchKernelGGL(k_sort_scatter<false>, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, vin,
+                               ctx->d_keys[out], ctx->d_vals[out], n, shift, ctx->d_block_hist, nblocks);
+        kin = ctx->d_keys[out];
+        vin = ctx->d_vals[out];
+        ctx->sorted_buf = out;
+        out ^= 1;
+    }
+    ctx->sort_passes = passes;
+    PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_SORT + 1], st));
+
+    if (want_tree) hipLaunchKernelGGL(k_radix_tree, dim3(grid_n), dim3(256), 0, st, n, ctx->d_tree);
+    PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_TOPOLOGY + 1], st));
+
+    const uint32_t *perm = ctx->d_vals[ctx->sorted_buf];
+    pt_TreeNode *tree = want_tree ? ctx->d_tree : nullptr;
+    const int nchunks = (int)(((long long)n + 1 + PT_REFIT_CHUNK - 1) / PT_REFIT_CHUNK);
+    hipLaunchKernelGGL(k_refit_low, dim3(nchunks), dim3(256), 0, st, perm, ctx->d_boxes, n, tree, ctx->d_wide, ctx->d_chunk);
+    const int top = bit_length((unsigned)n);
+    for (int k = PT_REFIT_CHUNK_LOG2 + 1; k <= top; k++) {
+        long long nb = (((long long)n + 1) + (1ll << k) - 1) >> k;
+        hipLaunchKernelGGL(k_refit_level, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, k, n, nb, tree, ctx->d_wide, ctx->d_chunk);
+    }
+    PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_REFIT + 1], st));
+
+    hipLaunchKernelGGL(k_pack_tris, dim3(grid_n), dim3(256), 0, st, prims16, n, ctx->d_tri, ctx->d_shade);
+    PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_PACK + 1], st));
+    PT_HIP(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+int ptk_export_sorted(pt_context *ctx, pt_PrimitiveRayCS *d_out)
+{
+    hipLaunchKernelGGL(k_export_sorted, dim3((ctx->n + 255) / 256), dim3(256), 0, ctx->stream,
+                       ctx->d_vals[ctx->sorted_buf], ctx->d_boxes, ctx->n, d_out);
+    PT_HIP(ctx, hipGetLastError());
+    return PT_OK;
+}

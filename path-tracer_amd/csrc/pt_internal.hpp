@@ -1,0 +1,130 @@
+// Internal declarations shared by the HIP translation units of libptamd.
+// Device-side layouts here are private to the library; the interchange layouts
+// are in include/ptamd_structs.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/ptamd.h"
+#include "../../include/ptamd_math.h"
+
+// ---- traversal layout -------------------------------------------------------
+// One record per INTERNAL node: the boxes of both children and the child ids.
+// A child id >= 0 is an internal node; a negative id is a leaf holding
+// primitive ~id.  The out-of-range leaf 2n of the reference tree (zero box,
+// primitive 0) is stored as id ~0 with the all-zero box.
+struct __attribute__((aligned(16))) WideNode {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    int32_t left, right;
+    int32_t pad[2];
+};
+static_assert(sizeof(WideNode) == 64, "WideNode is four 16-byte loads");
+
+// Triangle record for intersection: vertex a and the two edges (b-a, c-a are
+// pure functions of the vertices, so precomputing them changes no result).
+struct __attribute__((aligned(16))) TriIsect {
+    float a[3];  int32_t matid;
+    float e1[3]; float pad1;
+    float e2[3]; float pad2;
+};
+static_assert(sizeof(TriIsect) == 48, "TriIsect is three 16-byte loads");
+
+// Triangle record for shading: the three vertex normals.
+struct __attribute__((aligned(16))) TriShade {
+    float n0[3]; int32_t matid;
+    float n1[3]; float pad1;
+    float n2[3]; float pad2;
+};
+static_assert(sizeof(TriShade) == 48, "TriShade is three 16-byte loads");
+
+// Unsorted per-primitive box, same bytes as pt_PrimitiveRayCS {min, 0, max, index}
+struct __attribute__((aligned(16))) BoxRec {
+    float mn[3]; float pad;
+    float mx[3]; int32_t index;
+};
+static_assert(sizeof(BoxRec) == 32, "BoxRec");
+
+struct ChunkBox { float mn[3]; float mx[3]; };
+
+struct DevCounters {
+    unsigned long long paths, rays, node_visits, box_tests, tri_tests;
+};
+
+constexpr int PT_SORT_THREADS = 256;
+constexpr int PT_SORT_ITEMS = 16;
+constexpr int PT_SORT_TILE = PT_SORT_THREADS * PT_SORT_ITEMS;   // 4096 keys per workgroup
+constexpr int PT_REFIT_CHUNK_LOG2 = 10;
+constexpr int PT_REFIT_CHUNK = 1 << PT_REFIT_CHUNK_LOG2;        // 1024 sorted keys per workgroup
+
+struct pt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // scene
+    int n = 0;
+    const pt_PrimitiveRender *d_prims = nullptr;
+    bool prims_owned = false;
+    pt_CB_Radix cb{};
+    bool have_cb = false;
+    pt_CB_Radix *d_cb = nullptr;
+
+    // build products
+    bool built = false;
+    unsigned build_flags = 0;
+    int capacity = 0;                 // primitives the buffers below were sized for
+    BoxRec *d_boxes = nullptr;        // n
+    unsigned *d_bbox_enc = nullptr;   // 6 order-preserving encodings + padding
+    uint64_t *d_keys[2] = {nullptr, nullptr};
+    uint32_t *d_vals[2] = {nullptr, nullptr};
+    uint64_t *d_morton = nullptr;     // n, primitive order (kept for download)
+    int sorted_buf = 0;               // which of d_keys/d_vals holds the sorted result
+    uint32_t *d_block_hist = nullptr; // 256 * nblocks
+    uint32_t *d_digit_total = nullptr;// 8 * 256
+    pt_TreeNode *d_tree = nullptr;    // 2n+1
+    WideNode *d_wide = nullptr;       // n
+    ChunkBox *d_chunk = nullptr;      // ceil((n+1)/1024)
+    float *d_root = nullptr;          // the root's own box (6 floats)
+    TriIsect *d_tri = nullptr;        // n
+    TriShade *d_shade = nullptr;      // n
+    int sort_passes = 0;
+    hipEvent_t ev[PT_STAGE_COUNT + 1] = {};
+    bool have_events = false;
+
+    // images
+    int W = 0, H = 0;
+    uint8_t *d_diffuse = nullptr;     // RGBA8
+    float4 *d_normal = nullptr;       // xyz + asfloat(matid+1)
+    float4 *d_world = nullptr;
+    float4 *d_output = nullptr;       // gamma-space running average (`output` / `old`)
+    uint8_t *d_display = nullptr;     // RGBA8 (`output_u`)
+    float4 *d_linear = nullptr;       // linear sum, alpha = sample count
+    bool have_gbuffer = false;
+    uint32_t frame_count = 0;
+    uint32_t *d_seeds = nullptr;
+    std::vector<uint32_t> h_seeds;    // host staging that outlives the async copy
+    unsigned h_bbox_init[8] = {0xff800000u, 0xff800000u, 0xff800000u, 0x007fffffu, 0x007fffffu, 0x007fffffu, 0, 0};
+    uint32_t seeds_cap = 0;
+
+    // options / counters
+    int stack_entries = 0;            // 0 = automatic
+    bool detailed = false;
+    DevCounters *d_counters = nullptr;
+};
+
+#define PT_FAIL(ctx, code, msg) do { (ctx)->err = (msg); return (code); } while (0)
+#define PT_HIP(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_); return PT_ERR_HIP; } } while (0)
+
+// ---- launchers implemented in the kernel translation units ------------------
+int ptk_build(pt_context *ctx, unsigned flags);
+int ptk_root_box(pt_context *ctx);
+int ptk_export_sorted(pt_context *ctx, pt_PrimitiveRayCS *d_out);
+int ptk_primary(pt_context *ctx, const pt_camera *cam, const uint8_t *d_albedo);
+int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int mode);
+int ptk_resolve(pt_context *ctx);
+int ptk_intersect(pt_context *ctx, const float *d_rays8, int n_rays, pt_hit *d_out);
