@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json config 2): scene04 at 1162x1008, progressive accumulation with the
+fixed-seed convention.  One STEP = one block of 32 consecutive frames (one cycle of the shader's
+frame-index stratification) = 32 paths per pixel, traced by ONE launch of the path-trace kernel
+per GPU.  The default K = 32 steps is the 1024 spp of that config.  With N GPUs every rank holds
+the scene and its tree, traces its own blocks (weak scaling), and the float accumulation sums are
+merged by one RCCL all-reduce + resolve at the end, inside the timed region.
+
+value = BVH traversals (`intersect()` calls, counted by the kernel) of all ranks / wall time.
+Also measured, outside the timed trace region: the LBVH build on a 10M-triangle random soup
+(per GPU, replicas), and a bounded CPU baseline (the oracle, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, spec
+# algorithmic bytes of the traversal model: per node visit 24 B box + 8 B children + 4 B index,
+# per triangle test three positions = 36 B
+BYTES_PER_VISIT = 36
+BYTES_PER_TRI_TEST = 36
+# build: algorithmic bytes per triangle with 15-bit codes (two 8-bit sort passes):
+# boxes+codes 72, scene box 24, sort 8 + 2*24, gather 64, links 16, refit 144
+BUILD_BYTES_PER_TRI = 376
+
+
+def soup(n, seed=12345):
+    """Random triangle soup in the reference's PrimitiveRender layout."""
+    import ptamd
+    rng = np.random.default_rng(seed)
+    c = rng.random((n, 3), dtype=np.float32)
+    e = np.float32(0.5 * n ** (-1.0 / 3.0))
+    prims = np.zeros(n, dtype=ptamd.PRIM_RENDER)
+    prims["vertices"]["pos"][:, 0] = c
+    prims["vertices"]["pos"][:, 1] = c + (rng.random((n, 3), dtype=np.float32) * 2 - 1) * e
+    prims["vertices"]["pos"][:, 2] = c + (rng.random((n, 3), dtype=np.float32) * 2 - 1) * e
+    prims["vertices"]["normal"][:, :, 1] = 1.0
+    prims["pad"] = -1
+    return prims
+
+
+class _DevArray:
+    """Zero-copy view of library-owned device memory for torch (`__cuda_array_interface__`)."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def bench_build(ctx_factory, n, reps):
+    import ptamd
+    ctx = ctx_factory()
+    ctx.upload_primitives(soup(n))
+    times = []
+    for _ in range(reps + 1):
+        ctx.build()
+        times.append(ctx.build_times())
+    ctx.close()
+    times = times[1:]
+    tot = sorted(t["total"] - t["pack"] for t in times)[len(times) // 2]     # LBVH proper: bounds .. refit
+    med = {k: sorted(t[k] for t in times)[len(times) // 2] for k in ptamd.STAGES}
+    gbs = n * BUILD_BYTES_PER_TRI / (tot * 1e-3) / 1e9
+    return {
+        "workload": f"{n} random triangles (soup), 15-bit codes, 2 radix passes",
+        "mtris_per_s": n / (tot * 1e-3) / 1e6,
+        "ms": tot,
+        "stage_ms": med,
+        "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": gbs / HBM_PEAK_GBS, "bytes_per_tri": BUILD_BYTES_PER_TRI, "traffic": None},
+    }
+
+
+def cpu_baseline(g, W, H, budget_s=12.0, max_frames=8):
+    """The oracle (CPU restatement) on this host's cores, on whole frames of the same workload."""
+    from oracle import orc
+    threads = orc.n_threads() if "ORC_THREADS" in os.environ else max(1, min(16, os.cpu_count() or 1))
+    prims = g["prims"].view(orc.PRIM_RENDER)
+    cb = g["cb"].view(orc.CB_RADIX)
+    t0 = time.time()
+    ob = orc.build(prims)
+    build_s = time.time() - t0
+    sc = orc.OracleScene(prims, ob["tree"], cb)
+    kd = [list(m[0:3]) for m in g["mat_table"]] + [[0, 0, 0]] * (16 - len(g["mat_table"]))
+    gb = orc.primary(sc, orc.default_camera(), W, H, orc.albedo_table(cb, True, kd_override=kd), threads=threads)
+    acc = np.zeros((H, W, 4), np.float32)
+    seeds = orc.frame_seeds(1, 0, max_frames)
+    rays, frames = 0, 0
+    t0 = time.time()
+    while frames < max_frames and (time.time() - t0) < budget_s:
+        rays += orc.trace_frame_linear(sc, gb, frames, seeds[frames], acc, threads=threads)["rays"]
+        frames += 1
+    dt = time.time() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"scene04 {W}x{H}, frames 0..{frames - 1} ({rays} rays in {dt:.1f} s); "
+                      f"CPU LBVH build of its {len(prims)} triangles {build_s * 1e3:.1f} ms single-threaded"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="scene04")
+    ap.add_argument("--width", type=int, default=1162)
+    ap.add_argument("--height", type=int, default=1008)
+    ap.add_argument("--build-tris", type=int, default=10_000_000)
+    ap.add_argument("--no-build", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import ptamd
+    import ptdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if args.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    stream = torch.cuda.current_stream()
+
+    def make_ctx():
+        return ptamd.Context(local_rank, stream=stream.cuda_stream)
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", args.scene + ".npz"))
+    W, H = args.width, args.height
+    ctx = make_ctx()
+    ctx.upload_primitives(g["prims"].view(ptamd.PRIM_RENDER))
+    ctx.set_constants(g["cb"].view(ptamd.CB_RADIX))
+    ctx.build()
+    scene_build = ctx.build_times()
+    ctx.resize(W, H)
+    ctx.primary_hits(ptamd.default_camera(), ptamd.albedo_table(g["mat_table"][:, 0:3], True))
+    fpb = ptdist.FRAMES_PER_BLOCK
+    ptr, nbytes = ctx.linear_sum_ptr()
+    lin = torch.as_tensor(_DevArray(ptr, (H, W, 4)), device=torch.device("cuda", local_rank))
+    assert lin.data_ptr() == ptr and lin.numel() * 4 == nbytes
+
+    def step(s):
+        first, cnt = ptdist.block_frames(s, rank, world, fpb)
+        ctx.trace_frames(first, ptamd.frame_seeds(1, first, cnt), ptamd.PT_ACCUM_LINEAR)
+
+    # per-ray traversal statistics of this workload (instrumented kernel, one block): they
+    # turn the ray count into the algorithmic bytes of the roofline model
+    ctx.set_detailed_counters(True)
+    ctx.reset_counters()
+    step(0)
+    det = ctx.counters()
+    ctx.set_detailed_counters(False)
+    visits_per_ray = det["node_visits"] / det["rays"]
+    tris_per_ray = det["tri_tests"] / det["rays"]
+    bytes_per_ray = visits_per_ray * BYTES_PER_VISIT + tris_per_ray * BYTES_PER_TRI_TEST
+
+    for s in range(args.warmup):
+        step(s)
+    ctx.reset_accumulation()
+    ctx.reset_counters()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        ev[s][0].record(stream)
+        step(s)
+        ev[s][1].record(stream)
+    ptdist.reduce_linear_sum(lin, dist if world > 1 else None)
+    ctx.resolve()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+
+    cnt = ctx.counters()
+    tot = torch.tensor([dt, float(cnt["rays"]), float(cnt["paths"])], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = tot[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt = float(tmax.item())
+    rays, paths = float(tot[1].item()), float(tot[2].item())
+    kern_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+    rays_per_launch = cnt["rays"] / args.steps
+    achieved = rays_per_launch * bytes_per_ray / (kern_avg_ms * 1e-3) / 1e9
+
+    # sanity of the result image: every pixel saw every frame of the job
+    total_frames = ptdist.all_frames(args.steps, world, fpb)
+    alpha = lin[..., 3]
+    assert float(alpha.min().item()) == float(total_frames) == float(alpha.max().item()), "accumulation count mismatch"
+
+    build = None
+    if not args.no_build:
+        build = bench_build(make_ctx, args.build_tris, reps=5)
+        if world > 1:
+            b = torch.tensor([build["mtris_per_s"]], dtype=torch.float64, device="cuda")
+            dist.all_reduce(b, op=dist.ReduceOp.SUM)
+            build["mtris_per_s_all_gpus"] = float(b.item())
+            build["note"] = "replicas only: every GPU builds the whole soup"
+        else:
+            build["mtris_per_s_all_gpus"] = build["mtris_per_s"]
+
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_trace_pmc.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/s (whole node, scene04 1162x1008) + LBVH build Mtris/s @1/2/4/8 GPU",
+            "value": rays / dt / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": f"{args.scene} fixture (reference asset), fixed seeds mt19937(1), G-buffer by ray cast",
+            "config": {"workload": f"{args.scene}.obj {W}x{H}, {total_frames} spp progressive "
+                                   f"({args.steps} steps x {fpb} frames per GPU, linear-sum accumulation, "
+                                   f"RCCL all-reduce + resolve at the end)",
+                       "triangles": int(ctx.n), "parallelism": f"frames{world}"},
+            "mpaths_per_s": paths / dt / 1e6,
+            "rays_per_path": rays / paths,
+            "traversal": {"node_visits_per_ray": visits_per_ray, "tri_tests_per_ray": tris_per_ray,
+                          "bytes_per_ray": bytes_per_ray},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_trace", "launch_ms_avg": kern_avg_ms,
+                         "note": "tree + triangles (0.4 MB) are L2-resident: the kernel is VALU/latency bound, "
+                                 "the HBM fraction is reported because the contract asks for it"},
+            "scene_build_ms": scene_build["total"],
+        }
+        if build is not None:
+            out["build"] = build
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(g, W, H)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

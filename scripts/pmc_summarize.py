@@ -1,0 +1,20 @@
+"""Reads the per-pass counter CSVs of scripts/pmc_run.sh and writes a per-kernel summary (JSON + text)."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+src, out_json = sys.argv[1], sys.argv[2]
+acc = defaultdict(lambda: defaultdict(float)); calls = defaultdict(lambda: defaultdict(int))
+for f in glob.glob(os.path.join(src, "*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "").strip()
+        if r["Kernel_Name"].startswith("void (anonymous namespace)::k_trace") or "k_trace" in r["Kernel_Name"]:
+            k = "k_trace" + ("<detailed>" if "k_trace<true" in r["Kernel_Name"] else "")
+        if "k_sort_scatter" in r["Kernel_Name"]:
+            k = "k_sort_scatter"
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[k][r["Counter_Name"]] += 1
+res = {}
+for k in acc:
+    res[k] = {c: acc[k][c] / max(1, calls[k][c]) for c in acc[k]}
+    res[k]["_launches_seen"] = max(calls[k].values())
+json.dump(res, open(out_json, "w"), indent=1, sort_keys=True)
+for k in sorted(res):
+    print(k, {c: round(v, 1) for c, v in res[k].items()})

@@ -1,0 +1,270 @@
+"""GPU: G-buffer pass, traversal and path-trace kernel through the C ABI against the oracle.
+
+Bar: BIT-EXACT.  The library and the oracle evaluate the same IEEE-754 binary32 expressions
+(include/ptamd_math.h fixes sin/cos/pow/normalize), so radiance, accumulation images, display
+bytes and all counters must be identical; tolerance 0 (compared as raw bits).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import ptamd
+from oracle import orc
+from conftest import GOLDEN, SCENES, make_soup, soup_cb
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint8)
+
+
+def _setup(ctx, g, W, H, cam=None, quirk=True):
+    ctx.upload_primitives(g["prims"])
+    ctx.set_constants(g["cb"])
+    ctx.build()
+    ctx.resize(W, H)
+    alb = ptamd.albedo_table(g["mat_table"][:, 0:3], quirk)
+    ctx.primary_hits(cam or ptamd.default_camera(), alb)
+    sc = orc.OracleScene(g["prims"], g["tree"], g["cb"])
+    gb = orc.primary(sc, orc.default_camera(), W, H, alb)
+    return sc, gb, alb
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_gbuffer_bit_exact(gpu_ctx_factory, golden, scene):
+    ctx = gpu_ctx_factory()
+    sc, gb, alb = _setup(ctx, golden[scene], 200, 168)
+    d, n, w = ctx.download_gbuffer()
+    assert np.array_equal(d, gb[0])
+    assert np.array_equal(_bits(n), _bits(gb[1]))
+    assert np.array_equal(_bits(w), _bits(gb[2]))
+    assert (n[..., 3].view(np.int32) > 0).mean() > 0.5
+    assert np.array_equal(alb, orc.albedo_table(golden[scene]["cb"], True,
+                          kd_override=[list(m[0:3]) for m in golden[scene]["mat_table"]] + [[0, 0, 0]] * (16 - len(golden[scene]["mat_table"]))))
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_frames_bit_exact_literal(gpu_ctx_factory, golden, scene):
+    """pt_trace one frame at a time (the reference's run loop), then a multi-frame launch that
+    must continue the same recurrence; images, display bytes and counters equal the oracle's."""
+    W, H = 160, 136
+    ctx = gpu_ctx_factory()
+    sc, gb, _ = _setup(ctx, golden[scene], W, H)
+    ctx.set_detailed_counters(True)
+    seeds = ptamd.frame_seeds(1, 0, 7)
+    assert np.array_equal(seeds, orc.frame_seeds(1, 0, 7))
+    old = np.zeros((H, W, 4), np.float32)
+    tot = dict(paths=0, rays=0, node_visits=0, box_tests=0, tri_tests=0)
+    for f in range(3):
+        ctx.trace(f, seeds[f])
+        old, outu, _, c = orc.trace_frame(sc, gb, f, seeds[f], old)
+        tot = {k: tot[k] + c[k] for k in tot}
+        assert np.array_equal(_bits(ctx.output()), _bits(old)), f"frame {f}"
+        assert np.array_equal(ctx.display(), outu)
+    assert ctx.frame_count() == 3
+    ctx.trace_frames(3, seeds[3:], ptamd.PT_ACCUM_LITERAL)
+    for f in range(3, 7):
+        old, outu, _, c = orc.trace_frame(sc, gb, f, seeds[f], old)
+        tot = {k: tot[k] + c[k] for k in tot}
+    assert np.array_equal(_bits(ctx.output()), _bits(old))
+    assert np.array_equal(ctx.display(), outu)
+    assert ctx.frame_count() == 7
+    assert ctx.counters() == tot
+    assert tot["rays"] > tot["paths"] and tot["tri_tests"] > 0
+
+
+@pytest.mark.parametrize("scene", ["scene01", "scene04"])
+def test_frames_bit_exact_linear_and_late_frames(gpu_ctx_factory, golden, scene):
+    """Linear-sum mode, starting at a late frame index so that all stratification bits of
+    framecount (ray_tracing.hlsl:306-307,325-326) are exercised."""
+    W, H, first, N = 120, 104, 1000, 34
+    ctx = gpu_ctx_factory()
+    sc, gb, _ = _setup(ctx, golden[scene], W, H)
+    seeds = ptamd.frame_seeds(1, first, N)
+    ctx.trace_frames(first, seeds, ptamd.PT_ACCUM_LINEAR)
+    acc = np.zeros((H, W, 4), np.float32)
+    rays = 0
+    for i in range(N):
+        rays += orc.trace_frame_linear(sc, gb, first + i, seeds[i], acc)["rays"]
+    assert np.array_equal(_bits(ctx.linear_sum()), _bits(acc))
+    assert ctx.counters()["rays"] == rays and ctx.counters()["paths"] == W * H * N
+    ctx.resolve()
+    out, outu = orc.resolve(acc, N)
+    assert np.array_equal(_bits(ctx.output()), _bits(out))
+    assert np.array_equal(ctx.display(), outu)
+    # splitting the same frames over two launches changes nothing
+    ctx.reset_accumulation()
+    ctx.trace_frames(first, seeds[:10], ptamd.PT_ACCUM_LINEAR)
+    ctx.trace_frames(first + 10, seeds[10:], ptamd.PT_ACCUM_LINEAR)
+    assert np.array_equal(_bits(ctx.linear_sum()), _bits(acc))
+
+
+def test_uploaded_gbuffer_and_no_srgb_quirk(gpu_ctx_factory, golden):
+    """A G-buffer handed in from outside (the reference's rasteriser path) gives the same frames."""
+    W, H = 96, 80
+    g = golden["scene02"]
+    ctx = gpu_ctx_factory()
+    ctx.upload_primitives(g["prims"]); ctx.set_constants(g["cb"]); ctx.build(); ctx.resize(W, H)
+    sc = orc.OracleScene(g["prims"], g["tree"], g["cb"])
+    alb = ptamd.albedo_table(g["mat_table"][:, 0:3], srgb_quirk=False)
+    gb = orc.primary(sc, orc.default_camera(eye=(2.0, 6.0, 30.0), at=(0.0, 5.0, 8.0)), W, H, alb)
+    ctx.upload_gbuffer(*gb)
+    old = np.zeros((H, W, 4), np.float32)
+    for f, s in enumerate([11, 22, 33]):
+        ctx.trace(f, s)
+        old = orc.trace_frame(sc, gb, f, s, old)[0]
+    assert np.array_equal(_bits(ctx.output()), _bits(old))
+
+
+def test_intersect_queries_bit_exact(gpu_ctx_factory, golden):
+    g = golden["scene04"]
+    ctx = gpu_ctx_factory()
+    ctx.upload_primitives(g["prims"]); ctx.build()
+    sc = orc.OracleScene(g["prims"], g["tree"], g["cb"])
+    rng = np.random.default_rng(11)
+    lo, hi = g["bb"]["min"][0], g["bb"]["max"][0]
+    R = 3000
+    rays = np.zeros((R, 8), dtype=np.float32)
+    rays[:, 0:3] = lo + (hi - lo) * rng.random((R, 3))
+    d = rng.normal(size=(R, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 4:7] = d
+    rays[:, 3] = 1e-4; rays[:, 7] = 10000.0
+    rays[::7, 4] = 0.0                                      # zero direction components (1/0 slabs)
+    rays[::11, 5] = -0.0
+    rays[0, 0:3] = (3.0, 2.0, 1.0); rays[0, 4:7] = (-3.0, -2.0, -1.0)   # through the origin: zero-box leaf
+    rays[1, 4:7] = rays[1, 4:7] * 7.5                       # non-unit direction
+    hits = ctx.intersect(rays)
+    n_hit = 0
+    for i in range(R):
+        h, prim, bary, t, _ = orc.intersect_one(sc, rays[i, 0:3], rays[i, 4:7], rays[i, 3], rays[i, 7])
+        assert bool(hits["hit"][i]) == h, i
+        if h:
+            n_hit += 1
+            assert hits["primitive"][i] == prim
+            assert np.float32(hits["t"][i]).tobytes() == np.float32(t).tobytes()
+            assert np.array_equal(_bits(hits["bary"][i]), _bits(np.float32(bary)))
+    assert n_hit > R // 2
+
+
+def test_soup_scene_with_all_material_kinds(gpu_ctx_factory):
+    """A random soup deeper than the hand-made scenes (n = 12000 -> 14 levels, the deepest the
+    reference's 15-entry stack handles), materials cycling through diffuse / glossy / glass / emitter."""
+    n, W, H = 12000, 128, 96
+    prims = make_soup(n, seed=99)
+    prims["matid"] = np.arange(n) % 4
+    cb = soup_cb(n)
+    ob = orc.build(prims)
+    ctx = gpu_ctx_factory()
+    ctx.upload_primitives(prims); ctx.set_constants(cb); ctx.build(); ctx.resize(W, H)
+    ctx.set_stack_size(15)
+    kd = [list(cb["mats"][0][m]["kd"][:3]) for m in range(16)]
+    alb = ptamd.albedo_table(kd)
+    cam = ptamd.default_camera(eye=(0.5, 0.5, 3.0), at=(0.5, 0.5, 0.5))
+    ctx.primary_hits(cam, alb)
+    sc = orc.OracleScene(prims, ob["tree"], cb)
+    gb = orc.primary(sc, orc.default_camera(eye=(0.5, 0.5, 3.0), at=(0.5, 0.5, 0.5)), W, H, alb)
+    d, nn, w = ctx.download_gbuffer()
+    assert np.array_equal(d, gb[0]) and np.array_equal(_bits(nn), _bits(gb[1])) and np.array_equal(_bits(w), _bits(gb[2]))
+    seeds = ptamd.frame_seeds(7, 0, 4)
+    ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LITERAL)
+    old = np.zeros((H, W, 4), np.float32)
+    for f in range(4):
+        old = orc.trace_frame(sc, gb, f, seeds[f], old)[0]
+    assert np.array_equal(_bits(ctx.output()), _bits(old))
+    assert np.isfinite(old[..., :3]).mean() > 0.99
+
+
+def test_deep_tree_needs_opt_in(gpu_ctx_factory):
+    n = 40000                                               # 16 levels: beyond the reference's stack
+    prims = make_soup(n, seed=3)
+    ctx = gpu_ctx_factory()
+    ctx.upload_primitives(prims); ctx.set_constants(soup_cb(n)); ctx.build(); ctx.resize(64, 64)
+    ctx.primary_hits(ptamd.default_camera(eye=(0.5, 0.5, 3.0), at=(0.5, 0.5, 0.5)), ptamd.albedo_table([[0.5] * 3] * 16))
+    ctx.set_stack_size(15)
+    with pytest.raises(ptamd.PtError, match="deeper"):
+        ctx.trace(0, 1)
+    ctx.set_stack_size(32)
+    ctx.trace(0, 1)
+    # with a stack that never overflows, results equal the oracle run with a deep stack
+    ob = orc.build(prims)
+    sc = orc.OracleScene(prims, ob["tree"], soup_cb(n), stack_size=64)
+    gb = ctx.download_gbuffer()
+    old = orc.trace_frame(sc, gb, 0, 1, np.zeros((64, 64, 4), np.float32))[0]
+    assert np.array_equal(_bits(ctx.output()), _bits(old))
+
+
+@pytest.mark.parametrize("scene", ["scene01", "scene04"])
+def test_full_size_frames_bit_exact(gpu_ctx_factory, golden, scene):
+    """1162x1008 (the benchmark size), frames 0 and 1, fixed seeds: every pixel equal to the oracle."""
+    W, H = 1162, 1008
+    ctx = gpu_ctx_factory()
+    sc, gb, _ = _setup(ctx, golden[scene], W, H)
+    d, n, w = ctx.download_gbuffer()
+    assert np.array_equal(d, gb[0]) and np.array_equal(_bits(n), _bits(gb[1])) and np.array_equal(_bits(w), _bits(gb[2]))
+    seeds = ptamd.frame_seeds(1, 0, 2)
+    ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LITERAL)
+    old = np.zeros((H, W, 4), np.float32)
+    rays = 0
+    for f in range(2):
+        old, outu, _, c = orc.trace_frame(sc, gb, f, seeds[f], old)
+        rays += c["rays"]
+    assert np.array_equal(_bits(ctx.output()), _bits(old))
+    assert np.array_equal(ctx.display(), outu)
+    assert ctx.counters()["rays"] == rays
+
+
+def test_full_size_many_frames_properties(gpu_ctx_factory, golden):
+    """scene04, 1162x1008, 256 frames: the same frames as one launch, as eight launches and in
+    literal vs linear mode; linear alpha counts the samples; modes agree to the documented tolerance."""
+    W, H, N = 1162, 1008, 256
+    ctx = gpu_ctx_factory()
+    _setup(ctx, golden["scene04"], W, H)
+    seeds = ptamd.frame_seeds(1, 0, N)
+    ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LINEAR)
+    one = ctx.linear_sum()
+    c1 = ctx.counters()
+    ctx.reset_accumulation(); ctx.reset_counters()
+    for k in range(8):
+        ctx.trace_frames(32 * k, seeds[32 * k:32 * k + 32], ptamd.PT_ACCUM_LINEAR)
+    assert np.array_equal(_bits(ctx.linear_sum()), _bits(one))
+    assert ctx.counters() == c1 and c1["paths"] == W * H * N
+    assert np.all(one[..., 3] == N) and np.isfinite(one).all() and np.all(one[..., :3] >= 0)
+    ctx.resolve()
+    lin = ctx.output()
+    ctx.reset_accumulation()
+    ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LITERAL)
+    lit = ctx.output()
+    # per-frame gamma round trip vs one resolve: float rounding only
+    assert np.abs(lit[..., :3] - lin[..., :3]).max() < 2e-3
+    assert np.all(lit[..., 3] == 1.0)
+
+
+def test_converged_image_close_to_reference_snapshot(gpu_ctx_factory, golden):
+    """scene01 at 1162x1008 against the reference's one shipped output (24440 frames, unknown seeds,
+    rasterised primaries, camera as its author left it: the box edges sit ~8 px off the default
+    camera's).  Image-level agreement only: RMSE over the 8-bit image and per-channel brightness.
+    The brightness check also tells the two colour-target conventions apart: with the sRGB-encoded
+    albedo bytes the means agree to < 1.5 levels, with plain UNORM bytes they are ~5 levels low."""
+    from PIL import Image
+    W, H, N = 1162, 1008, 1024
+    ref = np.asarray(Image.open(os.path.join(GOLDEN, "reference_snapshot_1162x1008_frame24440.png")).convert("RGB")).astype(np.float64)
+    ctx = gpu_ctx_factory()
+    g = golden["scene01"]
+    _setup(ctx, g, W, H)
+    means = {}
+    for quirk in (True, False):
+        ctx.primary_hits(ptamd.default_camera(), ptamd.albedo_table(g["mat_table"][:, 0:3], quirk))
+        ctx.reset_accumulation()
+        for k in range(N // 128):
+            ctx.trace_frames(128 * k, ptamd.frame_seeds(1, 128 * k, 128), ptamd.PT_ACCUM_LINEAR)
+        ctx.resolve()
+        img = ctx.display()[..., :3].astype(np.float64)
+        rmse = np.sqrt(np.mean((img - ref) ** 2))
+        means[quirk] = np.abs(img.mean(axis=(0, 1)) - ref.mean(axis=(0, 1)))
+        print("srgb_quirk", quirk, "RMSE (8-bit levels)", rmse, "channel mean diff", means[quirk])
+        if quirk:
+            assert rmse < 18.0
+    assert means[True].max() < 1.5
+    assert means[False].min() > 3.0
