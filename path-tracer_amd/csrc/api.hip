@@ -3,6 +3,8 @@
 #include "pt_internal.hpp"
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -36,6 +38,7 @@ static void free_build(pt_context *ctx)
     dev_free(ctx->d_chunk);
     dev_free(ctx->d_tri);
     dev_free(ctx->d_shade);
+    dev_free(ctx->d_tri_sorted);
     ctx->capacity = 0;
     ctx->built = false;
 }
@@ -81,12 +84,14 @@ int pt_create(int device_ordinal, pt_context **out)
     }
     pt_context *ctx = new pt_context();
     ctx->device = device_ordinal;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     int rc = set_device(ctx);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_cb, 1);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_bbox_enc, 16);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_root, 8);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_digit_total, 8 * 256);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_counters, 1);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_work, 64);
     if (!rc) { hipError_t e2 = hipMemset(ctx->d_counters, 0, sizeof(DevCounters)); if (e2 != hipSuccess) rc = PT_ERR_HIP; }
     for (int i = 0; !rc && i <= PT_STAGE_COUNT; i++) {
         hipError_t e2 = hipEventCreate(&ctx->ev[i]);
@@ -107,7 +112,7 @@ void pt_destroy(pt_context *ctx)
     free_images(ctx);
     if (ctx->prims_owned) { void *p = const_cast<pt_PrimitiveRender *>(ctx->d_prims); if (p) (void)hipFree(p); }
     dev_free(ctx->d_cb); dev_free(ctx->d_bbox_enc); dev_free(ctx->d_root); dev_free(ctx->d_digit_total);
-    dev_free(ctx->d_counters); dev_free(ctx->d_seeds);
+    dev_free(ctx->d_counters); dev_free(ctx->d_seeds); dev_free(ctx->d_work);
     for (int i = 0; i <= PT_STAGE_COUNT; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     delete ctx;
 }
@@ -194,6 +199,7 @@ static int ensure_build_buffers(pt_context *ctx)
     if (!rc) rc = dev_alloc(ctx, &ctx->d_chunk, nchunks);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_tri, (size_t)n);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_shade, (size_t)n);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_tri_sorted, (size_t)n + 1);
     if (rc) { free_build(ctx); return rc; }
     ctx->capacity = n;
     return PT_OK;
@@ -209,6 +215,7 @@ int pt_build(pt_context *ctx, unsigned flags)
     ctx->built = false;
     if (int rc = ptk_build(ctx, flags)) return rc;
     if (int rc = ptk_root_box(ctx)) return rc;
+    if (int rc = ptk_sort_tris(ctx)) return rc;
     ctx->build_flags = flags;
     ctx->built = true;
     return PT_OK;
@@ -527,6 +534,9 @@ int pt_get_counters(pt_context *ctx, pt_counters *out)
     if (int rc = d2h(ctx, &h, ctx->d_counters, sizeof(h))) return rc;
     out->paths = h.paths; out->rays = h.rays; out->node_visits = h.node_visits;
     out->box_tests = h.box_tests; out->tri_tests = h.tri_tests;
+    if (getenv("PTAMD_PRINT_SCHED"))
+        fprintf(stderr, "sched: iters %llu int_lanes %llu leaf_rounds %llu leaf_lanes %llu at_leaf_wait %llu refills %llu idle_wait %llu no_pixel %llu\n",
+                h.sched[0], h.sched[1], h.sched[2], h.sched[3], h.sched[4], h.sched[5], h.sched[6], h.sched[7]);
     return PT_OK;
 }
 

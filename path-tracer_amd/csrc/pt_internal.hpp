@@ -52,6 +52,10 @@ struct ChunkBox { float mn[3]; float mx[3]; };
 
 struct DevCounters {
     unsigned long long paths, rays, node_visits, box_tests, tri_tests;
+    // wave-scheduling statistics of the instrumented trace kernel (diagnostics only):
+    // iterations, lanes expanding a node, triangle-test rounds, lanes testing, lanes waiting at
+    // a leaf, refill rounds, lanes waiting for a refill, lanes without a pixel
+    unsigned long long sched[8];
 };
 
 constexpr int PT_SORT_THREADS = 256;
@@ -91,6 +95,9 @@ struct pt_context {
     float *d_root = nullptr;          // the root's own box (6 floats)
     TriIsect *d_tri = nullptr;        // n
     TriShade *d_shade = nullptr;      // n
+    TriIsect *d_tri_sorted = nullptr; // n+1, leaf-key order, primitive id in the spare word
+    unsigned *d_work = nullptr;       // pixel queue head of the persistent trace kernel
+    int num_cus = 256;
     int sort_passes = 0;
     hipEvent_t ev[PT_STAGE_COUNT + 1] = {};
     bool have_events = false;
@@ -123,6 +130,7 @@ struct pt_context {
 // ---- launchers implemented in the kernel translation units ------------------
 int ptk_build(pt_context *ctx, unsigned flags);
 int ptk_root_box(pt_context *ctx);
+int ptk_sort_tris(pt_context *ctx);
 int ptk_export_sorted(pt_context *ctx, pt_PrimitiveRayCS *d_out);
 int ptk_primary(pt_context *ctx, const pt_camera *cam, const uint8_t *d_albedo);
 int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int mode);

@@ -18,6 +18,8 @@
 // pending right children (id + entry distance) on a per-lane LDS stack.
 #include "pt_internal.hpp"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int TRACE_THREADS = 256;
@@ -62,18 +64,22 @@ __device__ __forceinline__ float rand_next(uint32_t &s)
 
 // ray_tracing.hlsl:46-86 with the reciprocal direction hoisted out (it is a pure
 // function of the ray).  Returns t_min <= t_max; the caller compares entry
-// distance with the current hit distance.
+// distance with the current hit distance.  Per axis the (near, far) plane pair
+// is selected by the sign test on 1/d exactly as the shader does, then
+// (plane - origin) * (1/d) is evaluated on the pair with packed f32 math (two
+// IEEE operations per instruction; same results as the scalar form).
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bool slab(const float *mn, const float *mx, const pt_f3 &o, const pt_f3 &inv, float &t_entry)
 {
-    float t_xmin, t_xmax, t_ymin, t_ymax, t_zmin, t_zmax;
-    if (inv.x >= 0) { t_xmin = (mn[0] - o.x) * inv.x; t_xmax = (mx[0] - o.x) * inv.x; }
-    else            { t_xmin = (mx[0] - o.x) * inv.x; t_xmax = (mn[0] - o.x) * inv.x; }
-    if (inv.y >= 0) { t_ymin = (mn[1] - o.y) * inv.y; t_ymax = (mx[1] - o.y) * inv.y; }
-    else            { t_ymin = (mx[1] - o.y) * inv.y; t_ymax = (mn[1] - o.y) * inv.y; }
-    if (inv.z >= 0) { t_zmin = (mn[2] - o.z) * inv.z; t_zmax = (mx[2] - o.z) * inv.z; }
-    else            { t_zmin = (mx[2] - o.z) * inv.z; t_zmax = (mn[2] - o.z) * inv.z; }
-    float t_min = pt_max(t_xmin, pt_max(t_ymin, t_zmin));
-    float t_max = pt_min(t_xmax, pt_min(t_ymax, t_zmax));
+    v2f bx, by, bz;
+    if (inv.x >= 0) { bx.x = mn[0]; bx.y = mx[0]; } else { bx.x = mx[0]; bx.y = mn[0]; }
+    if (inv.y >= 0) { by.x = mn[1]; by.y = mx[1]; } else { by.x = mx[1]; by.y = mn[1]; }
+    if (inv.z >= 0) { bz.x = mn[2]; bz.y = mx[2]; } else { bz.x = mx[2]; bz.y = mn[2]; }
+    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+    const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+    const v2f tx = (bx - ox) * ix, ty = (by - oy) * iy, tz = (bz - oz) * iz;
+    float t_min = pt_max(tx.x, pt_max(ty.x, tz.x));
+    float t_max = pt_min(tx.y, pt_min(ty.y, tz.y));
     t_entry = t_min;
     return t_min <= t_max;
 }
@@ -280,7 +286,29 @@ __device__ __forceinline__ void lane_pixel(int &x, int &y)
 
 constexpr int MAX_ITR = 5;   // ray_tracing.hlsl:245-247
 
-// ray_tracing.hlsl:348-420 for `count` consecutive frames of one pixel.
+// ---------------------------------------------------------------------------
+// ray_tracing.hlsl:348-420 for `count` consecutive frames of one pixel, as a
+// wave-level state machine.
+//
+// A lane is either TRAVERSING (it owns a ray and a current node) or IDLE (its
+// ray is finished: it needs shading, a new ray, or the next frame's path).
+// Paths of a wave's 64 lanes have very different lengths, and a traversal step
+// is one of three different things (expand an internal node, test a triangle,
+// pop).  Run naively, each lane drags the whole wave through its own control
+// flow.  Instead the wave alternates between
+//   * a refill phase, entered when at least REFILL_T lanes are idle (or nobody
+//     traverses): idle lanes shade their hit, continue or end their path, start
+//     the next frame's path, and set up the next ray;
+//   * traversal iterations in which every traversing lane does the same thing:
+//     expand its internal node; triangle tests are postponed until at least
+//     LEAF_T lanes wait at a leaf (or no lane has an internal node left); one
+//     pop attempt per iteration.
+// Per lane the order of node visits, tests and random draws is exactly that of
+// the sequential loop, so results do not change.
+// ---------------------------------------------------------------------------
+constexpr int IDLE = (int)0x80000001;      // no ray in flight
+struct Tuning { int refill_t, leaf_t; };
+
 template <bool COUNT, bool LINEAR>
 __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, int H,
                                                          const uint8_t *__restrict__ diffuse_tex,
@@ -289,93 +317,230 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, in
                                                          uint32_t first_frame, uint32_t count,
                                                          const uint32_t *__restrict__ seeds,
                                                          float4 *__restrict__ output, uint8_t *__restrict__ display,
-                                                         float4 *__restrict__ linear, DevCounters *__restrict__ counters)
+                                                         float4 *__restrict__ linear, DevCounters *__restrict__ counters,
+                                                         Tuning tune)
 {
     extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];
     uint2 *stack = lds_stack + threadIdx.x;
-    const int stride = TRACE_THREADS;
+    constexpr int stride = TRACE_THREADS;
+    const int REFILL_T = tune.refill_t, LEAF_T = tune.leaf_t;
 
     int x, y;
     lane_pixel(x, y);
     LaneCounters cnt;
-    if (x < W && y < H) {
-        const size_t p = (size_t)y * (size_t)W + (size_t)x;
-        const uchar4 dif8 = reinterpret_cast<const uchar4 *>(diffuse_tex)[p];
-        const float4 nrm4 = normal_tex[p];
-        const float4 pos4 = world_tex[p];
-        const pt_Material *mats = sc.cb->mats;
+    const bool in_image = (x < W && y < H);
+    const size_t p = in_image ? (size_t)y * (size_t)W + (size_t)x : 0;
+    const pt_Material *mats = sc.cb->mats;
+    const float inv_gamma = 1 / 2.2f;
+
+    // per-pixel constants of the first bounce (ray_tracing.hlsl:349-367)
+    const uchar4 dif8 = reinterpret_cast<const uchar4 *>(diffuse_tex)[p];
+    const float4 nrm4 = normal_tex[p];
+    const float4 pos4 = world_tex[p];
+    const int matid0 = __float_as_int(nrm4.w) - 1;                  // asint(normal.w) - 1
+    const bool background = (matid0 < 0);
+    const pt_f3 hit_pos = pt_mk3(pos4.x, pos4.y, pos4.z);
+    pt_f3 multi0 = pt_mk3(dif8.x / 255.0f, dif8.y / 255.0f, dif8.z / 255.0f);
+    pt_f3 view0 = pt_mk3(0, 0, 0), normal0 = pt_mk3(0, 0, 0);
+    if (in_image && !background) {
         const pt_f3 g_pos = pt_mk3(sc.cb->pos.v[0], sc.cb->pos.v[1], sc.cb->pos.v[2]);
+        if (mats[matid0].ns > 1) multi0 = pt_mk3(1, 1, 1);
+        view0 = pt_normalize3(pt_sub3(hit_pos, g_pos));
+        normal0 = pt_normalize3(pt_mk3(nrm4.x, nrm4.y, nrm4.z));
+    }
+    // ray_tracing.hlsl:410: uint(launchIndex.x + launchIndex.y * viewportDims.x), in float
+    const uint32_t pixel_id = (uint32_t)((float)(uint32_t)x + (float)(uint32_t)y * (float)W);
+    const float root_mn[3] = {sc.root[0], sc.root[1], sc.root[2]}, root_mx[3] = {sc.root[3], sc.root[4], sc.root[5]};
 
-        const int matid0 = __float_as_int(nrm4.w) - 1;              // asint(normal.w) - 1
-        const bool background = (matid0 < 0);
-        const pt_f3 hit_pos = pt_mk3(pos4.x, pos4.y, pos4.z);
-        pt_f3 multi0 = pt_mk3(dif8.x / 255.0f, dif8.y / 255.0f, dif8.z / 255.0f);
-        pt_f3 view0 = pt_mk3(0, 0, 0), normal0 = pt_mk3(0, 0, 0);
-        if (!background) {
-            if (mats[matid0].ns > 1) multi0 = pt_mk3(1, 1, 1);
-            view0 = pt_normalize3(pt_sub3(hit_pos, g_pos));
-            normal0 = pt_normalize3(pt_mk3(nrm4.x, nrm4.y, nrm4.z));
+    float4 acc = make_float4(0, 0, 0, 0);
+    if (in_image) acc = LINEAR ? linear[p] : output[p];
+
+    auto accumulate = [&](const pt_f3 &color, uint32_t framecount) {
+        if (LINEAR) {
+            acc.x += color.x; acc.y += color.y; acc.z += color.z; acc.w += 1.0f;
+        } else {
+            // ray_tracing.hlsl:412-419
+            const float this_color[4] = {color.x, color.y, color.z, 1.0f};
+            const float old_factor = 1.0f * (float)framecount / (float)(framecount + 1);
+            const float new_factor = 1.0f / (float)(framecount + 1);
+            float o[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                o[k] = pt_powf(pt_powf(o[k], 2.2f) * old_factor + this_color[k] * new_factor, inv_gamma);
+            acc = make_float4(o[0], o[1], o[2], o[3]);
         }
-        // ray_tracing.hlsl:410: uint(launchIndex.x + launchIndex.y * viewportDims.x), in float
-        const uint32_t pixel_id = (uint32_t)((float)(uint32_t)x + (float)(uint32_t)y * (float)W);
+    };
 
-        float4 acc = LINEAR ? linear[p] : output[p];
-        const float inv_gamma = 1 / 2.2f;
+    // lane state
+    uint32_t f = 0;                       // next frame of this pixel
+    bool alive = in_image;                // frames left or a path in flight
+    bool path_active = false;             // a path of frame f is in flight
+    int cur = IDLE, sp = 0;
+    uint32_t seed = 0;
+    int itr = 1;
+    pt_f3 multi = pt_mk3(0, 0, 0);
+    Ray ray;
+    ray.o = hit_pos; ray.d = pt_mk3(0, 0, 1); ray.t_min = PT_EPSILON; ray.t_max = 10000;
+    pt_f3 inv = pt_mk3(1, 1, 1);
+    float current_t = 0;
+    bool intersected = false;
+    int hit_prim = 0;
+    float hit_bx = 0, hit_by = 0, hit_bz = 0;
 
-        for (uint32_t f = 0; f < count; f++) {
-            const uint32_t framecount = first_frame + f;
-            pt_f3 color = pt_mk3(0, 0, 0);
-            cnt.paths++;
-            if (!background) {
-                uint32_t seed = rand_init(pixel_id, seeds[f]);
-                pt_f3 multi = multi0, direction;
-                if (!get_bounce(mats, framecount, view0, normal0, matid0, multi, direction, seed)) {
-                    color = multi;
-                } else {
-                    Ray ray;
-                    ray.t_min = PT_EPSILON;
-                    ray.t_max = 10000;
-                    ray.o = hit_pos;
-                    ray.d = direction;
-                    int itr = 1, prim = 0;
-                    pt_f3 bary = pt_mk3(0, 0, 0);
-                    float t;
-                    while (traverse<COUNT>(sc, ray, stack, stride, prim, bary, t, cnt)) {
-                        ray.o = pt_add3(ray.o, pt_scale3(ray.d, t));
-                        itr++;
-                        const float4 *sp = reinterpret_cast<const float4 *>(&sc.shade[prim]);
-                        const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2];
-                        const int matid = __float_as_int(s0.w);
-                        if (itr > MAX_ITR) {
-                            const float pr = pt_max(pt_max(multi.x, multi.y), multi.z);
-                            if (pr > rand_next(seed)) multi = pt_scale3(multi, 1 / pr);
-                            else break;
+    if (alive && background) {
+        // ray_tracing.hlsl:361-362: black, but still accumulated every frame
+        for (uint32_t k = 0; k < count; k++) { cnt.paths++; accumulate(pt_mk3(0, 0, 0), first_frame + k); }
+        alive = false;
+    }
+
+    for (;;) {
+        // ------------------------------------------------------------ refill
+        const bool need = alive && cur == IDLE;
+        const unsigned long long need_mask = __ballot(need);
+        const unsigned long long trav_mask = __ballot(alive && cur != IDLE);
+        if (need_mask == 0 && trav_mask == 0) break;
+        if (need_mask != 0 && (__popcll(need_mask) >= REFILL_T || trav_mask == 0)) {
+            if (need) {
+                bool have_ray = false;
+                do {
+                    pt_f3 direction;
+                    bool cont = false;                      // path continues with `direction`
+                    if (path_active) {
+                        // back from intersect() (ray_tracing.hlsl:372-395)
+                        const uint32_t framecount = first_frame + f;
+                        pt_f3 color = pt_mk3(0, 0, 0);
+                        if (intersected) {
+                            ray.o = pt_add3(ray.o, pt_scale3(ray.d, current_t));
+                            itr++;
+                            const float4 *shp = reinterpret_cast<const float4 *>(&sc.shade[hit_prim]);
+                            const float4 s0 = shp[0], s1 = shp[1], s2 = shp[2];
+                            const int matid = __float_as_int(s0.w);
+                            bool ended = false;
+                            if (itr > MAX_ITR) {
+                                const float pr = pt_max(pt_max(multi.x, multi.y), multi.z);
+                                if (pr > rand_next(seed)) multi = pt_scale3(multi, 1 / pr);
+                                else ended = true;
+                            }
+                            if (!ended && itr >= MAX_ITR * 3) ended = true;
+                            if (!ended) {
+                                const pt_f3 A = pt_mk3(s0.x, s0.y, s0.z), B = pt_mk3(s1.x, s1.y, s1.z), C = pt_mk3(s2.x, s2.y, s2.z);
+                                const pt_f3 new_normal = pt_add3(pt_add3(pt_scale3(A, hit_bz), pt_scale3(B, hit_bx)), pt_scale3(C, hit_by));
+                                if (get_bounce(mats, framecount, ray.d, new_normal, matid, multi, direction, seed)) cont = true;
+                                else color = multi;
+                            }
                         }
-                        if (itr >= MAX_ITR * 3) break;
-                        const pt_f3 A = pt_mk3(s0.x, s0.y, s0.z), B = pt_mk3(s1.x, s1.y, s1.z), C = pt_mk3(s2.x, s2.y, s2.z);
-                        const pt_f3 new_normal = pt_add3(pt_add3(pt_scale3(A, bary.z), pt_scale3(B, bary.x)), pt_scale3(C, bary.y));
-                        if (!get_bounce(mats, framecount, ray.d, new_normal, matid, multi, direction, seed)) {
-                            color = multi;
-                            break;
+                        if (!cont) {
+                            accumulate(color, framecount);
+                            path_active = false;
+                            f++;
                         }
-                        ray.d = direction;
+                    } else if (f < count) {
+                        // new path of frame f (ray_tracing.hlsl:348-370, 410)
+                        const uint32_t framecount = first_frame + f;
+                        cnt.paths++;
+                        seed = rand_init(pixel_id, seeds[f]);
+                        multi = multi0;
+                        itr = 1;
+                        ray.o = hit_pos;
+                        if (get_bounce(mats, framecount, view0, normal0, matid0, multi, direction, seed)) {
+                            cont = true;
+                            path_active = true;
+                        } else {
+                            accumulate(multi, framecount);
+                            f++;
+                        }
+                    } else {
+                        alive = false;
                     }
+                    if (cont) {
+                        // start intersect() (ray_tracing.hlsl:191-214) with the root's own box test
+                        ray.d = direction;
+                        inv = pt_mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+                        current_t = ray.t_max;
+                        intersected = false;
+                        sp = 0;
+                        cnt.rays++;
+                        if (COUNT) { cnt.node_visits++; cnt.box_tests++; }
+                        float t_entry;
+                        if (slab(root_mn, root_mx, ray.o, inv, t_entry) && t_entry <= current_t) {
+                            cur = 0;
+                            have_ray = true;
+                        }
+                        // else: a miss; the loop handles it like any finished ray
+                    }
+                } while (alive && !have_ray);
+            }
+        }
+        // --------------------------------------------------------- traversal
+        for (;;) {
+            const bool trav = alive && cur != IDLE;
+            const unsigned long long tm = __ballot(trav);
+            if (tm == 0) break;
+            if (__popcll(__ballot(alive && cur == IDLE)) >= REFILL_T) break;
+            if (trav && cur >= 0) {
+                const float4 *w = reinterpret_cast<const float4 *>(&sc.wide[cur]);
+                const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+                const float lmn[3] = {w0.x, w0.y, w0.z}, lmx[3] = {w0.w, w1.x, w1.y};
+                const float rmn[3] = {w1.z, w1.w, w2.x}, rmx[3] = {w2.y, w2.z, w2.w};
+                const int left = __float_as_int(w3.x), right = __float_as_int(w3.y);
+                float tl, tr;
+                const bool hl = slab(lmn, lmx, ray.o, inv, tl) && tl <= current_t;
+                const bool hr = slab(rmn, rmx, ray.o, inv, tr) && tr <= current_t;
+                if (COUNT) { cnt.node_visits += 2; cnt.box_tests += 2; }
+                if (hl) {
+                    if (hr) { stack[sp * stride] = make_uint2((unsigned)right, __float_as_uint(tr)); sp++; }
+                    cur = left;
+                } else {
+                    cur = hr ? right : POP;
                 }
             }
-            if (LINEAR) {
-                acc.x += color.x; acc.y += color.y; acc.z += color.z; acc.w += 1.0f;
-            } else {
-                // ray_tracing.hlsl:412-419
-                const float this_color[4] = {color.x, color.y, color.z, 1.0f};
-                const float old_factor = 1.0f * (float)framecount / (float)(framecount + 1);
-                const float new_factor = 1.0f / (float)(framecount + 1);
-                float o[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    o[k] = pt_powf(pt_powf(o[k], 2.2f) * old_factor + this_color[k] * new_factor, inv_gamma);
-                acc = make_float4(o[0], o[1], o[2], o[3]);
+            const bool at_leaf = trav && cur < 0 && cur != POP;
+            const unsigned long long leaf_mask = __ballot(at_leaf);
+            if (leaf_mask != 0 && (__popcll(leaf_mask) >= LEAF_T || __ballot(trav && cur >= 0) == 0)) {
+                if (at_leaf) {
+                    const int prim = ~cur;
+                    const float4 *tp = reinterpret_cast<const float4 *>(&sc.tri[prim]);
+                    const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    if (COUNT) cnt.tri_tests++;
+                    // ray_tracing.hlsl:167-189
+                    const pt_f3 a = pt_mk3(t0.x, t0.y, t0.z), e_1 = pt_mk3(t1.x, t1.y, t1.z), e_2 = pt_mk3(t2.x, t2.y, t2.z);
+                    const pt_f3 q = pt_cross3(ray.d, e_2);
+                    const float a1 = pt_dot3(e_1, q);
+                    if (!(fabsf(a1) <= PT_EPSILON)) {
+                        const pt_f3 oa = pt_sub3(ray.o, a);
+                        const pt_f3 s = pt_mk3(oa.x / a1, oa.y / a1, oa.z / a1);
+                        const pt_f3 r = pt_cross3(s, e_1);
+                        const float t = pt_dot3(e_2, r);
+                        const float bx = pt_dot3(s, q);
+                        const float by = pt_dot3(r, ray.d);
+                        const float bz = 1 - bx - by;
+                        if (bx >= -PT_EPSILON && by >= -PT_EPSILON && bz >= -PT_EPSILON && t >= PT_EPSILON) {
+                            if (current_t > t && t > ray.t_min) {
+                                hit_bx = bx; hit_by = by; hit_bz = bz;
+                                current_t = t;
+                                hit_prim = prim;
+                                intersected = true;
+                            }
+                        }
+                    }
+                    cur = POP;
+                }
+            }
+            if (trav && cur == POP) {
+                // one pending child per iteration; entries whose entry distance no
+                // longer passes the distance test are dropped
+                if (sp == 0) {
+                    cur = IDLE;
+                } else {
+                    sp--;
+                    const uint2 e = stack[sp * stride];
+                    if (__uint_as_float(e.y) <= current_t) cur = (int)e.x;
+                }
             }
         }
+    }
+
+    if (in_image) {
         if (LINEAR) {
             linear[p] = acc;
         } else {
@@ -386,6 +551,361 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, in
         }
     }
     flush_counters(cnt, counters, COUNT);
+}
+
+// ---------------------------------------------------------------------------
+// The same state machine with the tree held in LDS, for scenes whose node
+// records fit (48 bytes per internal node: the two child boxes).
+//
+// Why: every node visit is a per-lane random 64-byte gather.  Through the vector
+// L1 that is one tag lookup per lane per 16 bytes, and the L1 tag pipeline
+// (about one access per clock per CU) becomes the limit long before the VALU
+// does.  LDS serves sixteen 16-byte lane reads per clock.
+//
+// Child ids are not stored.  The tree over keys 0..n is the binary trie of the
+// key indices, so a node is named by (first key s, level k): its left child is
+// (s, k-1) with record id s + 2^(k-1) - 1 (a left child's id is its last key),
+// its right child starts at s + 2^(k-1), ends at e = min(s + 2^k - 1, n), has
+// level bit_length(start ^ e) and record id = its first key; level 0 is a leaf
+// whose key indexes the triangle records in sorted order.  Pending right
+// children need no ids either: a per-lane bit mask records at which ancestor
+// levels one is pending, and the ancestor's first key is the current key with
+// its low bits cleared.  The LDS stack therefore holds only the entry distance,
+// one float per level.
+//
+// One persistent workgroup per CU; lanes take pixels from a global counter (64
+// consecutive pixels per wave request) and run all `count` frames of a pixel
+// before taking the next, so a wave never idles on a finished pixel.
+// ---------------------------------------------------------------------------
+constexpr int K_POP = -1, K_IDLE = -2;
+
+template <bool COUNT, bool LINEAR>
+__global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect *__restrict__ tri_sorted, int levels,
+                                                    int W, int H,
+                                                    const uint8_t *__restrict__ diffuse_tex,
+                                                    const float4 *__restrict__ normal_tex,
+                                                    const float4 *__restrict__ world_tex,
+                                                    uint32_t first_frame, uint32_t count,
+                                                    const uint32_t *__restrict__ seeds,
+                                                    float4 *__restrict__ output, uint8_t *__restrict__ display,
+                                                    float4 *__restrict__ linear, DevCounters *__restrict__ counters,
+                                                    unsigned *__restrict__ work_counter, Tuning tune)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 lds_nodes[];
+    const int n = sc.n;
+    const int nthreads = blockDim.x;
+    float *stack = reinterpret_cast<float *>(lds_nodes + 3 * n) + threadIdx.x;   // level L at stack[(L-1) * nthreads]
+    for (int i = threadIdx.x; i < 3 * n; i += nthreads) {
+        const int node = i / 3, part = i - 3 * node;
+        lds_nodes[i] = reinterpret_cast<const float4 *>(&sc.wide[node])[part];
+    }
+    __syncthreads();
+
+    const int REFILL_T = tune.refill_t, LEAF_T = tune.leaf_t;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const unsigned total_px = (unsigned)W * (unsigned)H;
+    const pt_Material *mats = sc.cb->mats;
+    const pt_f3 g_pos = pt_mk3(sc.cb->pos.v[0], sc.cb->pos.v[1], sc.cb->pos.v[2]);
+    const float inv_gamma = 1 / 2.2f;
+    const float root_mn[3] = {sc.root[0], sc.root[1], sc.root[2]}, root_mx[3] = {sc.root[3], sc.root[4], sc.root[5]};
+    LaneCounters cnt;
+    unsigned long long sched[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // wave-uniform pixel queue
+    unsigned q_next = 0, q_end = 0;
+    bool exhausted = false;
+
+    // per-pixel state
+    bool has_px = false;
+    unsigned px = 0;
+    int matid0 = 0;
+    pt_f3 hit_pos = pt_mk3(0, 0, 0), multi0 = pt_mk3(0, 0, 0), view0 = pt_mk3(0, 0, 0), normal0 = pt_mk3(0, 0, 0);
+    uint32_t pixel_id = 0;
+    float4 acc = make_float4(0, 0, 0, 0);
+    uint32_t f = 0;
+    // per-path / per-ray state
+    bool path_active = false;
+    int cur_k = K_IDLE, cur_s = 0, cur_id = 0;
+    unsigned pending = 0;
+    uint32_t seed = 0;
+    int itr = 1;
+    pt_f3 multi = pt_mk3(0, 0, 0);
+    Ray ray;
+    ray.o = hit_pos; ray.d = pt_mk3(0, 0, 1); ray.t_min = PT_EPSILON; ray.t_max = 10000;
+    pt_f3 inv = pt_mk3(1, 1, 1);
+    float current_t = 0;
+    bool intersected = false;
+    int hit_prim = 0;
+    float hit_bx = 0, hit_by = 0, hit_bz = 0;
+
+    auto accumulate = [&](const pt_f3 &color, uint32_t framecount) {
+        if (LINEAR) {
+            acc.x += color.x; acc.y += color.y; acc.z += color.z; acc.w += 1.0f;
+        } else {
+            // ray_tracing.hlsl:412-419
+            const float this_color[4] = {color.x, color.y, color.z, 1.0f};
+            const float old_factor = 1.0f * (float)framecount / (float)(framecount + 1);
+            const float new_factor = 1.0f / (float)(framecount + 1);
+            float o[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                o[k] = pt_powf(pt_powf(o[k], 2.2f) * old_factor + this_color[k] * new_factor, inv_gamma);
+            acc = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    };
+    auto store_pixel = [&]() {
+        if (LINEAR) {
+            linear[px] = acc;
+        } else {
+            output[px] = acc;
+            reinterpret_cast<uchar4 *>(display)[px] =
+                make_uchar4((unsigned char)to_unorm8(acc.x), (unsigned char)to_unorm8(acc.y),
+                            (unsigned char)to_unorm8(acc.z), (unsigned char)to_unorm8(acc.w));
+        }
+    };
+
+    for (;;) {
+        // ------------------------------------------------------------ refill
+        const bool need = (has_px && cur_k == K_IDLE) || (!has_px && !exhausted);
+        const unsigned long long need_mask = __ballot(need);
+        const unsigned long long trav_mask = __ballot(has_px && cur_k >= K_POP);
+        if (need_mask == 0 && trav_mask == 0) break;
+        if (need_mask != 0 && (__popcll(need_mask) >= REFILL_T || trav_mask == 0)) {
+            if (COUNT) sched[5]++;
+            for (int pass = 0; pass < 2; pass++) {
+                // ---- take new pixels
+                bool want = !has_px && !exhausted;
+                unsigned long long wm = __ballot(want);
+                while (wm != 0) {
+                    if (q_next == q_end) {
+                        unsigned base = 0;
+                        if (lane == 0) base = atomicAdd(work_counter, 64u);
+                        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                        if (base >= total_px) { exhausted = true; break; }
+                        q_next = base;
+                        q_end = min(base + 64u, total_px);
+                    }
+                    const unsigned rank = (unsigned)__popcll(wm & lt_mask);
+                    const unsigned avail = q_end - q_next;
+                    if (want && rank < avail) {
+                        px = q_next + rank;
+                        const unsigned y = px / (unsigned)W, x = px - y * (unsigned)W;
+                        const uchar4 dif8 = reinterpret_cast<const uchar4 *>(diffuse_tex)[px];
+                        const float4 nrm4 = normal_tex[px];
+                        const float4 pos4 = world_tex[px];
+                        acc = LINEAR ? linear[px] : output[px];
+                        matid0 = __float_as_int(nrm4.w) - 1;            // asint(normal.w) - 1
+                        if (matid0 < 0) {
+                            // ray_tracing.hlsl:361-362: black, but still accumulated every frame
+                            for (uint32_t k = 0; k < count; k++) { cnt.paths++; accumulate(pt_mk3(0, 0, 0), first_frame + k); }
+                            store_pixel();
+                        } else {
+                            hit_pos = pt_mk3(pos4.x, pos4.y, pos4.z);
+                            multi0 = pt_mk3(dif8.x / 255.0f, dif8.y / 255.0f, dif8.z / 255.0f);
+                            if (mats[matid0].ns > 1) multi0 = pt_mk3(1, 1, 1);
+                            view0 = pt_normalize3(pt_sub3(hit_pos, g_pos));
+                            normal0 = pt_normalize3(pt_mk3(nrm4.x, nrm4.y, nrm4.z));
+                            // ray_tracing.hlsl:410: uint(launchIndex.x + launchIndex.y * viewportDims.x), in float
+                            pixel_id = (uint32_t)((float)x + (float)y * (float)W);
+                            f = 0;
+                            path_active = false;
+                            cur_k = K_IDLE;
+                            has_px = true;
+                            want = false;
+                        }
+                    }
+                    q_next += min((unsigned)__popcll(wm), avail);
+                    wm = __ballot(want);
+                }
+                // ---- shade finished rays, continue / end / start paths
+                if (has_px && cur_k == K_IDLE) {
+                    bool have_ray = false;
+                    do {
+                        pt_f3 direction;
+                        bool cont = false, bounce = false, terminate = false;
+                        const uint32_t framecount = first_frame + f;
+                        pt_f3 color = pt_mk3(0, 0, 0), b_view = view0, b_normal = normal0;
+                        int b_mat = matid0;
+                        if (path_active) {
+                            // back from intersect() (ray_tracing.hlsl:372-395)
+                            terminate = true;
+                            if (intersected) {
+                                ray.o = pt_add3(ray.o, pt_scale3(ray.d, current_t));
+                                itr++;
+                                const float4 *shp = reinterpret_cast<const float4 *>(&sc.shade[hit_prim]);
+                                const float4 s0 = shp[0], s1 = shp[1], s2 = shp[2];
+                                bool ended = false;
+                                if (itr > MAX_ITR) {
+                                    const float pr = pt_max(pt_max(multi.x, multi.y), multi.z);
+                                    if (pr > rand_next(seed)) multi = pt_scale3(multi, 1 / pr);
+                                    else ended = true;
+                                }
+                                if (!ended && itr >= MAX_ITR * 3) ended = true;
+                                if (!ended) {
+                                    const pt_f3 A = pt_mk3(s0.x, s0.y, s0.z), B = pt_mk3(s1.x, s1.y, s1.z), C = pt_mk3(s2.x, s2.y, s2.z);
+                                    b_normal = pt_add3(pt_add3(pt_scale3(A, hit_bz), pt_scale3(B, hit_bx)), pt_scale3(C, hit_by));
+                                    b_view = ray.d;
+                                    b_mat = __float_as_int(s0.w);
+                                    bounce = true;
+                                    terminate = false;
+                                }
+                            }
+                        } else if (f < count) {
+                            // new path of frame f (ray_tracing.hlsl:348-370, 410)
+                            cnt.paths++;
+                            seed = rand_init(pixel_id, seeds[f]);
+                            multi = multi0;
+                            itr = 1;
+                            ray.o = hit_pos;
+                            path_active = true;
+                            bounce = true;
+                        } else {
+                            store_pixel();
+                            has_px = false;
+                        }
+                        if (bounce) {
+                            // one call site: lanes continuing a path and lanes starting one shade together
+                            if (get_bounce(mats, framecount, b_view, b_normal, b_mat, multi, direction, seed)) cont = true;
+                            else { color = multi; terminate = true; }
+                        }
+                        if (terminate) {
+                            accumulate(color, framecount);
+                            path_active = false;
+                            f++;
+                        }
+                        if (cont) {
+                            // start intersect() (ray_tracing.hlsl:191-214) with the root's own box test
+                            ray.d = direction;
+                            inv = pt_mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+                            current_t = ray.t_max;
+                            intersected = false;
+                            pending = 0;
+                            cnt.rays++;
+                            if (COUNT) { cnt.node_visits++; cnt.box_tests++; }
+                            float t_entry;
+                            if (slab(root_mn, root_mx, ray.o, inv, t_entry) && t_entry <= current_t) {
+                                cur_k = levels; cur_s = 0; cur_id = 0;
+                                have_ray = true;
+                            }
+                        }
+                    } while (has_px && !have_ray);
+                }
+                if (__ballot(!has_px && !exhausted) == 0) break;
+            }
+        }
+        // --------------------------------------------------------- traversal
+        for (;;) {
+            const bool trav = has_px && cur_k >= K_POP;
+            if (__ballot(trav) == 0) break;
+            if (__popcll(__ballot((has_px && cur_k == K_IDLE) || (!has_px && !exhausted))) >= REFILL_T) break;
+            if (COUNT) {
+                sched[0]++;
+                sched[1] += __popcll(__ballot(trav && cur_k >= 1));
+                sched[4] += __popcll(__ballot(trav && cur_k == 0));                     // waiting at a leaf
+                sched[6] += __popcll(__ballot(has_px && cur_k == K_IDLE));             // waiting for a refill
+                sched[7] += __popcll(__ballot(!has_px));                               // no pixel (queue empty)
+            }
+            if (trav && cur_k >= 1) {
+                const float4 *w = lds_nodes + 3 * cur_id;
+                const float4 w0 = w[0], w1 = w[1], w2 = w[2];
+                const float lmn[3] = {w0.x, w0.y, w0.z}, lmx[3] = {w0.w, w1.x, w1.y};
+                const float rmn[3] = {w1.z, w1.w, w2.x}, rmx[3] = {w2.y, w2.z, w2.w};
+                float tl, tr;
+                const bool hl = slab(lmn, lmx, ray.o, inv, tl) && tl <= current_t;
+                const bool hr = slab(rmn, rmx, ray.o, inv, tr) && tr <= current_t;
+                if (COUNT) { cnt.node_visits += 2; cnt.box_tests += 2; }
+                const int k = cur_k, half = 1 << (k - 1);
+                if (hl) {
+                    if (hr) { stack[(k - 1) * nthreads] = tr; pending |= 1u << k; }
+                    cur_k = k - 1;
+                    cur_id = cur_s + half - 1;
+                } else if (hr) {
+                    const int sr = cur_s + half, e = min(cur_s + 2 * half - 1, n);
+                    cur_k = 32 - __clz(sr ^ e);
+                    cur_s = sr;
+                    cur_id = sr;
+                } else {
+                    cur_k = K_POP;
+                }
+            }
+            const bool at_leaf = trav && cur_k == 0;
+            const unsigned long long leaf_mask = __ballot(at_leaf);
+            if (leaf_mask != 0 && (__popcll(leaf_mask) >= LEAF_T || __ballot(trav && cur_k >= 1) == 0)) {
+                if (COUNT) { sched[2]++; sched[3] += __popcll(leaf_mask); }
+                if (at_leaf) {
+                    const float4 *tp = reinterpret_cast<const float4 *>(&tri_sorted[cur_s]);
+                    const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    if (COUNT) cnt.tri_tests++;
+                    // ray_tracing.hlsl:167-189
+                    const pt_f3 a = pt_mk3(t0.x, t0.y, t0.z), e_1 = pt_mk3(t1.x, t1.y, t1.z), e_2 = pt_mk3(t2.x, t2.y, t2.z);
+                    const pt_f3 q = pt_cross3(ray.d, e_2);
+                    const float a1 = pt_dot3(e_1, q);
+                    if (!(fabsf(a1) <= PT_EPSILON)) {
+                        const pt_f3 oa = pt_sub3(ray.o, a);
+                        const pt_f3 s = pt_mk3(oa.x / a1, oa.y / a1, oa.z / a1);
+                        const pt_f3 r = pt_cross3(s, e_1);
+                        const float t = pt_dot3(e_2, r);
+                        const float bx = pt_dot3(s, q);
+                        const float by = pt_dot3(r, ray.d);
+                        const float bz = 1 - bx - by;
+                        if (bx >= -PT_EPSILON && by >= -PT_EPSILON && bz >= -PT_EPSILON && t >= PT_EPSILON) {
+                            if (current_t > t && t > ray.t_min) {
+                                hit_bx = bx; hit_by = by; hit_bz = bz;
+                                current_t = t;
+                                hit_prim = __float_as_int(t0.w);
+                                intersected = true;
+                            }
+                        }
+                    }
+                    cur_k = K_POP;
+                }
+            }
+            if (trav && cur_k == K_POP) {
+                // up to two pending children per iteration: entries whose entry distance no
+                // longer passes the distance test are dropped
+#pragma unroll
+                for (int attempt = 0; attempt < 2; attempt++) {
+                    if (cur_k != K_POP) break;
+                    if (pending == 0) {
+                        cur_k = K_IDLE;
+                    } else {
+                        const int L = __ffs((int)pending) - 1;          // deepest pending ancestor level
+                        pending &= pending - 1;
+                        const float t_entry = stack[(L - 1) * nthreads];
+                        if (t_entry <= current_t) {
+                            const int sa = (cur_s >> L) << L, half = 1 << (L - 1);
+                            const int sr = sa + half, e = min(sa + 2 * half - 1, n);
+                            cur_k = 32 - __clz(sr ^ e);
+                            cur_s = sr;
+                            cur_id = sr;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    flush_counters(cnt, counters, COUNT);
+    if (COUNT && lane == 0) {
+        for (int k = 0; k < 8; k++) atomicAdd(&counters->sched[k], sched[k]);
+    }
+}
+
+// triangle records in sorted (leaf key) order, primitive id in the spare word;
+// entry n belongs to the out-of-range leaf (primitive 0)
+__global__ __launch_bounds__(256) void k_sort_tris(const TriIsect *__restrict__ tri, const uint32_t *__restrict__ perm, int n,
+                                                   TriIsect *__restrict__ out)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j > n) return;
+    const int p = (j < n) ? (int)perm[j] : 0;
+    const float4 *src = reinterpret_cast<const float4 *>(&tri[p]);
+    float4 *dst = reinterpret_cast<float4 *>(&out[j]);
+    float4 r0 = src[0];
+    r0.w = __int_as_float(p);
+    dst[0] = r0;
+    dst[1] = src[1];
+    dst[2] = src[2];
 }
 
 // out = pow(sum.rgb / sum.a, 1/2.2), alpha 1
@@ -519,16 +1039,60 @@ static size_t stack_bytes(const pt_context *ctx)
     return (size_t)TRACE_THREADS * sizeof(uint2) * (size_t)(levels + 1 <= 16 ? 16 : 32);
 }
 
+int ptk_sort_tris(pt_context *ctx)
+{
+    hipLaunchKernelGGL(k_sort_tris, dim3((ctx->n + 1 + 255) / 256), dim3(256), 0, ctx->stream,
+                       ctx->d_tri, ctx->d_vals[ctx->sorted_buf], ctx->n, ctx->d_tri_sorted);
+    PT_HIP(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+// Largest workgroup (multiple of 64, at most 1024 threads) whose per-level stack fits
+// beside the node records in the CU's 160 KiB of LDS; 0 when the tree does not fit.
+static int lds_resident_threads(const pt_context *ctx, int *levels_out, size_t *bytes_out)
+{
+    const size_t lds_total = 160 * 1024;
+    const int levels = 32 - __builtin_clz((unsigned)ctx->n | 1u);
+    const size_t nodes = (size_t)ctx->n * 48;
+    if (nodes + (size_t)levels * 4 * 256 > lds_total) return 0;
+    size_t t = (lds_total - nodes) / ((size_t)levels * 4);
+    t = t > 1024 ? 1024 : (t / 64) * 64;
+    *levels_out = levels;
+    *bytes_out = nodes + (size_t)levels * 4 * t;
+    return (int)t;
+}
+
 int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int mode)
 {
     SceneView sv;
     if (int rc = make_view(ctx, sv)) return rc;
+    Tuning tune = {24, 12};
+    if (const char *e = getenv("PTAMD_REFILL_T")) tune.refill_t = atoi(e);
+    if (const char *e = getenv("PTAMD_LEAF_T")) tune.leaf_t = atoi(e);
+    const bool lin = (mode == PT_ACCUM_LINEAR);
+    int levels = 0;
+    size_t lds_bytes = 0;
+    int threads = lds_resident_threads(ctx, &levels, &lds_bytes);
+    if (const char *e = getenv("PTAMD_NO_LDS_TREE")) if (atoi(e)) threads = 0;
+    if (const char *e = getenv("PTAMD_LDS_THREADS")) { int t = atoi(e); if (t >= 64 && t <= threads) { threads = (t / 64) * 64; lds_bytes = (size_t)ctx->n * 48 + (size_t)levels * 4 * threads; } }
+    if (threads >= 256) {
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
+#define PT_LAUNCH_LDS(C, L) do { \
+        PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_lds<C, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+        hipLaunchKernelGGL((k_trace_lds<C, L>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
+            ctx->W, ctx->H, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first_frame, count, ctx->d_seeds, \
+            ctx->d_output, ctx->d_display, ctx->d_linear, ctx->d_counters, ctx->d_work, tune); } while (0)
+        if (ctx->detailed) { if (lin) PT_LAUNCH_LDS(true, true); else PT_LAUNCH_LDS(true, false); }
+        else               { if (lin) PT_LAUNCH_LDS(false, true); else PT_LAUNCH_LDS(false, false); }
+#undef PT_LAUNCH_LDS
+        PT_HIP(ctx, hipGetLastError());
+        return PT_OK;
+    }
     dim3 grid((ctx->W + 15) / 16, (ctx->H + 15) / 16), block(TRACE_THREADS);
     const size_t lds = stack_bytes(ctx);
 #define PT_LAUNCH_TRACE(C, L) hipLaunchKernelGGL((k_trace<C, L>), grid, block, lds, ctx->stream, sv, ctx->W, ctx->H, \
         ctx->d_diffuse, ctx->d_normal, ctx->d_world, first_frame, count, ctx->d_seeds, \
-        ctx->d_output, ctx->d_display, ctx->d_linear, ctx->d_counters)
-    const bool lin = (mode == PT_ACCUM_LINEAR);
+        ctx->d_output, ctx->d_display, ctx->d_linear, ctx->d_counters, tune)
     if (ctx->detailed) { if (lin) PT_LAUNCH_TRACE(true, true); else PT_LAUNCH_TRACE(true, false); }
     else               { if (lin) PT_LAUNCH_TRACE(false, true); else PT_LAUNCH_TRACE(false, false); }
 #undef PT_LAUNCH_TRACE

@@ -5,7 +5,7 @@ src, out_json = sys.argv[1], sys.argv[2]
 acc = defaultdict(lambda: defaultdict(float)); calls = defaultdict(lambda: defaultdict(int))
 for f in glob.glob(os.path.join(src, "*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "").strip()
+        k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip()
         if r["Kernel_Name"].startswith("void (anonymous namespace)::k_trace") or "k_trace" in r["Kernel_Name"]:
             k = "k_trace" + ("<detailed>" if "k_trace<true" in r["Kernel_Name"] else "")
         if "k_sort_scatter" in r["Kernel_Name"]:
