@@ -69,6 +69,9 @@ int pt_set_constants(pt_context *ctx, const pt_CB_Radix *cb);
 #define PT_BUILD_DEFAULT        0u
 #define PT_BUILD_MORTON_FULL    1u   /* NON-PARITY: quantise to 2^21 cells per axis instead of the reference's 22 */
 #define PT_BUILD_NO_TREE_EXPORT 2u   /* skip writing the reference-layout TreeNode[2n] array (kept: the traversal layout) */
+#define PT_BUILD_KARRAS_LINKS   4u   /* also run the search-based link kernel (the direct counterpart of
+                                        radix_build_cs.hlsl); by default the links come from the closed form of
+                                        the index-keyed tree inside the refit kernels -- same values */
 int pt_build(pt_context *ctx, unsigned flags);
 
 typedef enum pt_build_stage {

@@ -29,6 +29,7 @@ static void dev_free(T *&p)
 static void free_build(pt_context *ctx)
 {
     dev_free(ctx->d_boxes);
+    dev_free(ctx->d_bbox_partial);
     dev_free(ctx->d_keys[0]); dev_free(ctx->d_keys[1]);
     dev_free(ctx->d_vals[0]); dev_free(ctx->d_vals[1]);
     dev_free(ctx->d_morton);
@@ -188,6 +189,7 @@ static int ensure_build_buffers(pt_context *ctx)
     const size_t nblocks = ((size_t)n + PT_SORT_TILE - 1) / PT_SORT_TILE;
     const size_t nchunks = ((size_t)n + 1 + PT_REFIT_CHUNK - 1) / PT_REFIT_CHUNK;
     int rc = dev_alloc(ctx, &ctx->d_boxes, (size_t)n);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_bbox_partial, 6 * (((size_t)n + 255) / 256));
     if (!rc) rc = dev_alloc(ctx, &ctx->d_keys[0], (size_t)n);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_keys[1], (size_t)n);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_vals[0], (size_t)n);
@@ -209,7 +211,7 @@ int pt_build(pt_context *ctx, unsigned flags)
 {
     if (!ctx) return PT_ERR_INVALID;
     if (!ctx->d_prims || ctx->n < 1) PT_FAIL(ctx, PT_ERR_INVALID, "pt_build: no primitives uploaded");
-    if (flags & ~(PT_BUILD_MORTON_FULL | PT_BUILD_NO_TREE_EXPORT)) PT_FAIL(ctx, PT_ERR_INVALID, "pt_build: unknown flag");
+    if (flags & ~(PT_BUILD_MORTON_FULL | PT_BUILD_NO_TREE_EXPORT | PT_BUILD_KARRAS_LINKS)) PT_FAIL(ctx, PT_ERR_INVALID, "pt_build: unknown flag");
     if (int rc = set_device(ctx)) return rc;
     if (int rc = ensure_build_buffers(ctx)) return rc;
     ctx->built = false;

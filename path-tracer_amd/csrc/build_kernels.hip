@@ -47,7 +47,7 @@ __device__ __forceinline__ float wave_max(float v)
 constexpr int PRIM_DW = 20;   // dwords per PrimitiveRender
 
 __global__ __launch_bounds__(256) void k_bounds(const uint4 *__restrict__ prims16, int n,
-                                                BoxRec *__restrict__ boxes, unsigned *__restrict__ bbox_enc)
+                                                BoxRec *__restrict__ boxes, float *__restrict__ partial)
 {
     __shared__ uint4 stage[256 * PRIM_DW / 4];      // 20480 B
     __shared__ float red[6][4];
@@ -88,12 +88,32 @@ __global__ __launch_bounds__(256) void k_bounds(const uint4 *__restrict__ prims1
         if (lane == 0) { red[k][wave] = a; red[3 + k][wave] = b; }
     }
     __syncthreads();
-    if (t < 3) {
-        float a = fminf(fminf(red[t][0], red[t][1]), fminf(red[t][2], red[t][3]));
-        atomicMin(&bbox_enc[t], enc_f(a));
-    } else if (t < 6) {
-        float b = fmaxf(fmaxf(red[t][0], red[t][1]), fmaxf(red[t][2], red[t][3]));
-        atomicMax(&bbox_enc[t], enc_f(b));
+    // one partial box per workgroup; a second, single-workgroup kernel merges them (tens of
+    // thousands of workgroups hammering six atomics would serialise at the memory side)
+    if (t < 3) partial[(size_t)blockIdx.x * 6 + t] = fminf(fminf(red[t][0], red[t][1]), fminf(red[t][2], red[t][3]));
+    else if (t < 6) partial[(size_t)blockIdx.x * 6 + t] = fmaxf(fmaxf(red[t][0], red[t][1]), fmaxf(red[t][2], red[t][3]));
+}
+
+__global__ __launch_bounds__(1024) void k_bbox_reduce(const float *__restrict__ partial, int nparts, unsigned *__restrict__ bbox_enc)
+{
+    __shared__ float red[6][16];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const float inf = __uint_as_float(0x7f800000u);
+    float v[6] = {inf, inf, inf, -inf, -inf, -inf};
+    for (int i = t; i < nparts; i += 1024) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { v[k] = fminf(v[k], partial[(size_t)i * 6 + k]); v[3 + k] = fmaxf(v[3 + k], partial[(size_t)i * 6 + 3 + k]); }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float a = wave_min(v[k]), b = wave_max(v[3 + k]);
+        if (lane == 0) { red[k][wave] = a; red[3 + k][wave] = b; }
+    }
+    __syncthreads();
+    if (t < 6) {
+        float r = red[t][0];
+        for (int w = 1; w < 16; w++) r = (t < 3) ? fminf(r, red[t][w]) : fmaxf(r, red[t][w]);
+        bbox_enc[t] = enc_f(r);
     }
 }
 
@@ -140,8 +160,7 @@ __global__ __launch_bounds__(256) void k_morton(const BoxRec *__restrict__ boxes
 //                             reorder, coalesced runs out)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(PT_SORT_THREADS) void k_sort_hist(const uint64_t *__restrict__ keys, int n, int shift,
-                                                               uint32_t *__restrict__ block_hist,
-                                                               uint32_t *__restrict__ digit_total, int nblocks)
+                                                               uint32_t *__restrict__ block_hist, int nblocks)
 {
     __shared__ uint32_t h[256];
     const int t = threadIdx.x;
@@ -154,9 +173,7 @@ __global__ __launch_bounds__(PT_SORT_THREADS) void k_sort_hist(const uint64_t *_
         if (g < n) atomicAdd(&h[(unsigned)(keys[g] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    uint32_t c = h[t];
-    block_hist[(size_t)t * nblocks + blockIdx.x] = c;
-    if (c) atomicAdd(&digit_total[t], c);
+    block_hist[(size_t)t * nblocks + blockIdx.x] = h[t];
 }
 
 __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t x, uint32_t *sh /*[5]*/, uint32_t *total)
@@ -177,15 +194,14 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t x, uint32_t *sh
     return off + v - x;
 }
 
+// workgroup d turns row d (the counts of digit d per sorting workgroup) into exclusive
+// offsets within the digit and leaves the digit's total in digit_total[d]
 __global__ __launch_bounds__(256) void k_sort_scan(uint32_t *__restrict__ block_hist,
-                                                   const uint32_t *__restrict__ digit_total, int nblocks)
+                                                   uint32_t *__restrict__ digit_total, int nblocks)
 {
     __shared__ uint32_t sh[5];
     const int d = blockIdx.x, t = threadIdx.x;
-    uint32_t tot;
-    uint32_t mine = (t < d) ? digit_total[t] : 0u;
-    (void)block_excl_scan_256(mine, sh, &tot);      // tot = sum of totals of lower digits
-    uint32_t carry = tot;
+    uint32_t carry = 0;
     uint32_t *row = block_hist + (size_t)d * nblocks;
     for (int c = 0; c < nblocks; c += 256) {
         int i = c + t;
@@ -195,14 +211,16 @@ __global__ __launch_bounds__(256) void k_sort_scan(uint32_t *__restrict__ block_
         if (i < nblocks) row[i] = carry + ex;
         carry += sum;
     }
+    if (t == 0) digit_total[d] = carry;
 }
 
 template <bool IOTA>
 __global__ __launch_bounds__(PT_SORT_THREADS) void k_sort_scatter(
     const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int n, int shift,
-    const uint32_t *__restrict__ block_off, int nblocks)
+    const uint32_t *__restrict__ block_off, const uint32_t *__restrict__ digit_total, int nblocks)
 {
+    __shared__ uint32_t digit_gbase[256];               // first output slot of each digit
     __shared__ uint64_t skeys[PT_SORT_TILE];            // 32 KB
     __shared__ uint32_t svals[PT_SORT_TILE];            // 16 KB
     __shared__ uint32_t wave_hist[4][256];              //  4 KB
@@ -253,6 +271,7 @@ __global__ __launch_bounds__(PT_SORT_THREADS) void k_sort_scatter(
         uint32_t tot = c0 + c1 + c2 + c3, dummy;
         wave_hist[0][t] = 0; wave_hist[1][t] = c0; wave_hist[2][t] = c0 + c1; wave_hist[3][t] = c0 + c1 + c2;
         digit_base[t] = block_excl_scan_256(tot, sh, &dummy);
+        digit_gbase[t] = block_excl_scan_256(digit_total[t], sh, &dummy);
     }
     __syncthreads();
 #pragma unroll
@@ -266,7 +285,7 @@ __global__ __launch_bounds__(PT_SORT_THREADS) void k_sort_scatter(
     for (int i = t; i < tile_cnt; i += PT_SORT_THREADS) {
         uint64_t k = skeys[i];
         uint32_t d = (uint32_t)(k >> shift) & 255u;
-        uint32_t dst = block_off[(size_t)d * nblocks + blockIdx.x] + ((uint32_t)i - digit_base[d]);
+        uint32_t dst = digit_gbase[d] + block_off[(size_t)d * nblocks + blockIdx.x] + ((uint32_t)i - digit_base[d]);
         keys_out[dst] = k;
         vals_out[dst] = svals[i];
     }
@@ -339,17 +358,30 @@ __device__ __forceinline__ void write_wide(WideNode *__restrict__ w, const float
     dst[3] = make_float4(__int_as_float(left), __int_as_float(right), 0.0f, 0.0f);
 }
 
-__device__ __forceinline__ void write_tree_box(pt_TreeNode *__restrict__ node, int index, const float *U)
-{   // fields index, bound, padding (bytes 12..47); left/right/parent belong to k_radix_tree
-    node->index = index;
-    node->bound.min.v[0] = U[0]; node->bound.min.v[1] = U[1]; node->bound.min.v[2] = U[2];
-    node->bound.padding0 = 0.0f;
-    node->bound.max.v[0] = U[3]; node->bound.max.v[1] = U[4]; node->bound.max.v[2] = U[5];
-    node->padding = 0;
+// parent of the node at (level k, block b): the nearest ancestor block that is a node.  The
+// block one level up is a node when we are its right half (b odd) or when its right half is
+// not empty; otherwise every ancestor that has us in its left half has an empty right half, and
+// the parent is the first ancestor that has us in its right half.
+__device__ __forceinline__ int parent_id(long long b, int k, int n, int top)
+{
+    if (k == top) return 0;                           // the root keeps parent 0
+    if ((b & 1) || ((b + 1) << k) <= (long long)n) return node_id(b >> 1, k + 1, n);
+    const int m = __ffsll((unsigned long long)b);     // b even, non-zero here
+    return node_id(b >> m, k + m, n);
+}
+
+// one whole 48-byte record of the reference layout: left, right, parent, index, box, padding
+__device__ __forceinline__ void write_tree_node(pt_TreeNode *__restrict__ node, int left, int right, int parent,
+                                                int index, const float *U)
+{
+    float4 *dst = reinterpret_cast<float4 *>(node);
+    dst[0] = make_float4(__int_as_float(left), __int_as_float(right), __int_as_float(parent), __int_as_float(index));
+    dst[1] = make_float4(U[0], U[1], U[2], 0.0f);
+    dst[2] = make_float4(U[3], U[4], U[5], 0.0f);
 }
 
 __global__ __launch_bounds__(256) void k_refit_low(const uint32_t *__restrict__ perm, const BoxRec *__restrict__ boxes,
-                                                   int n, pt_TreeNode *__restrict__ tree, WideNode *__restrict__ wide,
+                                                   int n, int top, pt_TreeNode *__restrict__ tree, WideNode *__restrict__ wide,
                                                    ChunkBox *__restrict__ chunk)
 {
     __shared__ float sb[6][PT_REFIT_CHUNK];          // 24 KB: min.xyz, max.xyz per key slot
@@ -365,12 +397,7 @@ __global__ __launch_bounds__(256) void k_refit_low(const uint32_t *__restrict__ 
             const float4 *src = reinterpret_cast<const float4 *>(&boxes[p]);
             float4 lo = src[0], hi = src[1];
             b[0] = lo.x; b[1] = lo.y; b[2] = lo.z; b[3] = hi.x; b[4] = hi.y; b[5] = hi.z;
-            if (tree) {
-                pt_TreeNode *leaf = &tree[(long long)n + key];
-                leaf->left = 0;
-                leaf->right = 0;
-                write_tree_box(leaf, p, b);
-            }
+            if (tree) write_tree_node(&tree[(long long)n + key], 0, 0, node_id(key >> 1, 1, n), p, b);
         }
 #pragma unroll
         for (int c = 0; c < 6; c++) sb[c][j] = b[c];
@@ -396,7 +423,9 @@ __global__ __launch_bounds__(256) void k_refit_low(const uint32_t *__restrict__ 
                 const int left = (k == 1) ? ~sprim[ls] : (int)gamma;
                 const int right = (gamma + 1 == e) ? ~sprim[rs] : (int)(gamma + 1);
                 write_wide(&wide[id], L, R, left, right);
-                if (tree) write_tree_box(&tree[id], 0, U);
+                if (tree)
+                    write_tree_node(&tree[id], (k == 1) ? n + (int)s : (int)gamma,
+                                    (gamma + 1 == e) ? n + (int)gamma + 1 : (int)(gamma + 1), parent_id(b, k, n, top), 0, U);
 #pragma unroll
                 for (int c = 0; c < 6; c++) sb[c][ls] = U[c];
             }
@@ -406,7 +435,7 @@ __global__ __launch_bounds__(256) void k_refit_low(const uint32_t *__restrict__ 
     if (t < 6) (&chunk[blockIdx.x].mn[0])[t] = sb[t][0];
 }
 
-__global__ __launch_bounds__(256) void k_refit_level(int k, int n, long long nblocks_level,
+__global__ __launch_bounds__(256) void k_refit_level(int k, int n, int top, long long nblocks_level,
                                                      pt_TreeNode *__restrict__ tree, WideNode *__restrict__ wide,
                                                      ChunkBox *__restrict__ chunk)
 {
@@ -427,7 +456,7 @@ __global__ __launch_bounds__(256) void k_refit_level(int k, int n, long long nbl
     // above chunk level a single-key right range can only be key n itself
     const int right = (gamma + 1 == e) ? ~0 : (int)(gamma + 1);
     write_wide(&wide[id], L, R, (int)gamma, right);
-    if (tree) write_tree_box(&tree[id], 0, U);
+    if (tree) write_tree_node(&tree[id], (int)gamma, (gamma + 1 == e) ? n + (int)gamma + 1 : (int)(gamma + 1), parent_id(b, k, n, top), 0, U);
 #pragma unroll
     for (int c = 0; c < 3; c++) { cl->mn[c] = U[c]; cl->mx[c] = U[3 + c]; }
 }
@@ -490,13 +519,11 @@ int ptk_build(pt_context *ctx, unsigned flags)
     const uint4 *prims16 = reinterpret_cast<const uint4 *>(ctx->d_prims);
 
     // scene-box accumulators: +inf encodings for the minima, -inf for the maxima
-    // (h_bbox_init: enc(+inf) = 0xff800000 three times, enc(-inf) = 0x007fffff three times)
-    PT_HIP(ctx, hipMemcpyAsync(ctx->d_bbox_enc, ctx->h_bbox_init, sizeof(ctx->h_bbox_init), hipMemcpyHostToDevice, st));
-    PT_HIP(ctx, hipMemsetAsync(ctx->d_digit_total, 0, 8 * 256 * sizeof(uint32_t), st));
     if (want_tree) PT_HIP(ctx, hipMemsetAsync(&ctx->d_tree[2 * (size_t)n], 0, sizeof(pt_TreeNode), st));
 
     PT_HIP(ctx, hipEventRecord(ctx->ev[0], st));
-    hipLaunchKernelGGL(k_bounds, dim3(grid_n), dim3(256), 0, st, prims16, n, ctx->d_boxes, ctx->d_bbox_enc);
+    hipLaunchKernelGGL(k_bounds, dim3(grid_n), dim3(256), 0, st, prims16, n, ctx->d_boxes, ctx->d_bbox_partial);
+    hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(1024), 0, st, ctx->d_bbox_partial, grid_n, ctx->d_bbox_enc);
     PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_BOUNDS + 1], st));
 
     const bool full = (flags & PT_BUILD_MORTON_FULL) != 0;
@@ -515,14 +542,14 @@ int ptk_build(pt_context *ctx, unsigned flags)
     for (int p = 0; p < passes; p++) {
         const int shift = 8 * p;
         uint32_t *dtot = ctx->d_digit_total + 256 * p;
-        hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, n, shift, ctx->d_block_hist, dtot, nblocks);
+        hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, n, shift, ctx->d_block_hist, nblocks);
         hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, st, ctx->d_block_hist, dtot, nblocks);
         if (p == 0)
             hipLaunchKernelGGL(k_sort_scatter<true>, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, vin,
-                               ctx->d_keys[out], ctx->d_vals[out], n, shift, ctx->d_block_hist, nblocks);
+                               ctx->d_keys[out], ctx->d_vals[out], n, shift, ctx->d_block_hist, dtot, nblocks);
         else
             hipLaunchKernelGGL(k_sort_scatter<false>, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, vin,
-                               ctx->d_keys[out], ctx->d_vals[out], n, shift, ctx->d_block_hist, nblocks);
+                               ctx->d_keys[out], ctx->d_vals[out], n, shift, ctx->d_block_hist, dtot, nblocks);
         kin = ctx->d_keys[out];
         vin = ctx->d_vals[out];
         ctx->sorted_buf = out;
@@ -531,18 +558,22 @@ int ptk_build(pt_context *ctx, unsigned flags)
     ctx->sort_passes = passes;
     PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_SORT + 1], st));
 
-    if (want_tree) hipLaunchKernelGGL(k_radix_tree, dim3(grid_n), dim3(256), 0, st, n, ctx->d_tree);
+    // Links (left / right / parent) are written by the refit kernels from the closed form of
+    // the index-keyed tree.  PT_BUILD_KARRAS_LINKS additionally runs the search-based kernel,
+    // which writes the same values (kept as the direct counterpart of radix_build_cs.hlsl).
+    const bool karras = want_tree && (flags & PT_BUILD_KARRAS_LINKS);
     PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_TOPOLOGY + 1], st));
 
     const uint32_t *perm = ctx->d_vals[ctx->sorted_buf];
     pt_TreeNode *tree = want_tree ? ctx->d_tree : nullptr;
     const int nchunks = (int)(((long long)n + 1 + PT_REFIT_CHUNK - 1) / PT_REFIT_CHUNK);
-    hipLaunchKernelGGL(k_refit_low, dim3(nchunks), dim3(256), 0, st, perm, ctx->d_boxes, n, tree, ctx->d_wide, ctx->d_chunk);
     const int top = bit_length((unsigned)n);
+    hipLaunchKernelGGL(k_refit_low, dim3(nchunks), dim3(256), 0, st, perm, ctx->d_boxes, n, top, tree, ctx->d_wide, ctx->d_chunk);
     for (int k = PT_REFIT_CHUNK_LOG2 + 1; k <= top; k++) {
         long long nb = (((long long)n + 1) + (1ll << k) - 1) >> k;
-        hipLaunchKernelGGL(k_refit_level, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, k, n, nb, tree, ctx->d_wide, ctx->d_chunk);
+        hipLaunchKernelGGL(k_refit_level, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, k, n, top, nb, tree, ctx->d_wide, ctx->d_chunk);
     }
+    if (karras) hipLaunchKernelGGL(k_radix_tree, dim3(grid_n), dim3(256), 0, st, n, ctx->d_tree);
     PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_REFIT + 1], st));
 
     hipLaunchKernelGGL(k_pack_tris, dim3(grid_n), dim3(256), 0, st, prims16, n, ctx->d_tri, ctx->d_shade);

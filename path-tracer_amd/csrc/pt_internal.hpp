@@ -83,6 +83,7 @@ struct pt_context {
     int capacity = 0;                 // primitives the buffers below were sized for
     BoxRec *d_boxes = nullptr;        // n
     unsigned *d_bbox_enc = nullptr;   // 6 order-preserving encodings + padding
+    float *d_bbox_partial = nullptr;  // 6 floats per bounds workgroup
     uint64_t *d_keys[2] = {nullptr, nullptr};
     uint32_t *d_vals[2] = {nullptr, nullptr};
     uint64_t *d_morton = nullptr;     // n, primitive order (kept for download)
@@ -114,7 +115,6 @@ struct pt_context {
     uint32_t frame_count = 0;
     uint32_t *d_seeds = nullptr;
     std::vector<uint32_t> h_seeds;    // host staging that outlives the async copy
-    unsigned h_bbox_init[8] = {0xff800000u, 0xff800000u, 0xff800000u, 0x007fffffu, 0x007fffffu, 0x007fffffu, 0, 0};
     uint32_t seeds_cap = 0;
 
     // options / counters

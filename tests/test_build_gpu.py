@@ -53,6 +53,23 @@ def test_soup_build_bit_exact(gpu_ctx_factory, n):
     _assert_build_equals(ctx, orc.build(prims))
 
 
+@pytest.mark.parametrize("n", [1, 2, 7, 862, 1025, 2416, 65537, 1000003])
+def test_closed_form_links_equal_search_kernel(gpu_ctx_factory, n):
+    """Links written from the closed form of the index-keyed tree (default) and by the
+    search-based kernel that follows radix_build_cs.hlsl are the same, and equal the oracle's."""
+    prims = make_soup(n, seed=n)
+    ctx = gpu_ctx_factory()
+    ctx.upload_primitives(prims)
+    ctx.build()
+    a = ctx.tree()
+    ctx.build(ptamd.PT_BUILD_KARRAS_LINKS)
+    b = ctx.tree()
+    assert a.tobytes() == b.tobytes()
+    o = orc.radix_tree(n)
+    for f in ("left", "right", "parent"):
+        assert np.array_equal(a[f], o[f][:2 * n]), f
+
+
 def test_rebuild_and_context_reuse(gpu_ctx_factory, golden):
     ctx = gpu_ctx_factory()
     for scene in ("scene04", "scene01", "scene04"):      # shrinking and growing n on one context
