@@ -1,0 +1,75 @@
+"""GPU: the RayTracer host class (same method names as the reference's) drives the C ABI and
+gives the oracle's results; the headless driver writes a snapshot."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ptamd
+from oracle import orc
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+LIB = os.path.join(ROOT, "path-tracer_amd", "libpthost.so")
+
+
+def test_raytracer_class_matches_oracle(golden, monkeypatch):
+    monkeypatch.chdir(os.path.join(GOLDEN, "scenes"))
+    L = C.CDLL(LIB)
+    L.pth_tracer_new.restype = C.c_void_p
+    L.pth_tracer_error.restype = C.c_char_p
+    for f in ("pth_tracer_free", "pth_tracer_error"):
+        getattr(L, f).argtypes = [C.c_void_p]
+    L.pth_tracer_load.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+    L.pth_tracer_run.argtypes = [C.c_void_p, C.c_int]
+    L.pth_tracer_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pth_tracer_members.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    W, H, frames = 144, 120, 3
+    r = L.pth_tracer_new(0)
+    try:
+        g = golden["scene04"]
+        n = L.pth_tracer_load(r, b"scene04.obj", W, H)
+        assert n == len(g["prims"]), L.pth_tracer_error(r)
+        # public members filled from the device build: bb_, ray_primitives (sorted), tree
+        bb = np.zeros(1, dtype=orc.BOUND)
+        rays = np.zeros(n, dtype=orc.PRIM_RAY)
+        tree = np.zeros(2 * n, dtype=orc.TREENODE)
+        assert L.pth_tracer_members(r, bb.ctypes.data_as(C.c_void_p), rays.ctypes.data_as(C.c_void_p),
+                                    tree.ctypes.data_as(C.c_void_p)) == 0
+        ob = orc.build(g["prims"])
+        assert np.array_equal(bb["min"], ob["bb"]["min"]) and np.array_equal(bb["max"], ob["bb"]["max"])
+        assert np.array_equal(rays["morton_code"], ob["sorted_rays"]["morton_code"])
+        assert np.array_equal(rays["index"], ob["sorted_rays"]["index"])
+        assert tree.tobytes() == ob["tree"][:2 * n].tobytes()
+        # run(): first call builds, every call traces one frame with the fixed-seed convention
+        assert L.pth_tracer_run(r, frames) == frames, L.pth_tracer_error(r)
+        out = np.zeros((H, W, 4), np.float32)
+        disp = np.zeros((H, W, 4), np.uint8)
+        assert L.pth_tracer_read(r, out.ctypes.data_as(C.c_void_p), disp.ctypes.data_as(C.c_void_p)) == 0
+        sc = orc.OracleScene(g["prims"], ob["tree"], g["cb"])          # golden cb = CS.cpp material mapping
+        kd = [list(m[0:3]) for m in g["mat_table"]] + [[0, 0, 0]] * (16 - len(g["mat_table"]))
+        gb = orc.primary(sc, orc.default_camera(), W, H, orc.albedo_table(g["cb"], True, kd_override=kd))
+        old = np.zeros((H, W, 4), np.float32)
+        seeds = orc.frame_seeds(1, 0, frames)
+        for f in range(frames):
+            old, outu, _, _ = orc.trace_frame(sc, gb, f, seeds[f], old)
+        assert out.tobytes() == old.tobytes()
+        assert np.array_equal(disp, outu)
+    finally:
+        L.pth_tracer_free(r)
+
+
+def test_headless_driver_writes_snapshot(tmp_path):
+    exe = os.path.join(ROOT, "path-tracer_amd", "host", "pt_headless")
+    out = tmp_path / "snap.bmp"
+    res = subprocess.run([exe, "scene01.obj", "160", "128", "8", str(out)], cwd=os.path.join(GOLDEN, "scenes"),
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    assert "862 triangles" in res.stdout
+    data = out.read_bytes()
+    assert data[:2] == b"BM" and len(data) == 54 + 160 * 3 * 128
+    assert max(data[54:]) > 100                          # the light is visible
+    bad = subprocess.run([exe, "missing.obj"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "cannot open" in bad.stderr
