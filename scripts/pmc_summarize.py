@@ -6,7 +6,9 @@ acc = defaultdict(lambda: defaultdict(float)); calls = defaultdict(lambda: defau
 for f in glob.glob(os.path.join(src, "*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip()
-        if r["Kernel_Name"].startswith("void (anonymous namespace)::k_trace") or "k_trace" in r["Kernel_Name"]:
+        if "k_trace_lds" in r["Kernel_Name"]:
+            k = "k_trace_lds" + ("<detailed>" if "k_trace_lds<true" in r["Kernel_Name"] else "")
+        elif "k_trace" in r["Kernel_Name"]:
             k = "k_trace" + ("<detailed>" if "k_trace<true" in r["Kernel_Name"] else "")
         if "k_sort_scatter" in r["Kernel_Name"]:
             k = "k_sort_scatter"
@@ -15,6 +17,11 @@ res = {}
 for k in acc:
     res[k] = {c: acc[k][c] / max(1, calls[k][c]) for c in acc[k]}
     res[k]["_launches_seen"] = max(calls[k].values())
+    if "FETCH_SIZE" in res[k] and "WRITE_SIZE" in res[k]:
+        # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-B read requests as 64 B,
+        # i.e. reads exactly half of a wide streaming read: doubled here (upper bound for narrow gathers)
+        res[k]["hbm_bytes_per_launch"] = (2.0 * res[k]["FETCH_SIZE"] + res[k]["WRITE_SIZE"]) * 1024.0
+        res[k]["hbm_bytes_per_launch_uncorrected"] = (res[k]["FETCH_SIZE"] + res[k]["WRITE_SIZE"]) * 1024.0
 json.dump(res, open(out_json, "w"), indent=1, sort_keys=True)
 for k in sorted(res):
     print(k, {c: round(v, 1) for c, v in res[k].items()})
