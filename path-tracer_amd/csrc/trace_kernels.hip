@@ -718,40 +718,45 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                     q_next += min((unsigned)__popcll(wm), avail);
                     wm = __ballot(want);
                 }
-                // ---- shade finished rays, continue / end / start paths
+                // ---- shade finished rays, continue / end / start paths: ONE pass, so that the
+                // expensive parts (first-bounce set-up, get_bounce, ray set-up) run once per round for
+                // all idle lanes together; a lane left without a ray is served by the next round
                 if (has_px && cur_k == K_IDLE) {
-                    bool have_ray = false;
-                    do {
-                        pt_f3 direction;
-                        bool cont = false, bounce = false, terminate = false;
-                        const uint32_t framecount = first_frame + f;
-                        pt_f3 color = pt_mk3(0, 0, 0), b_view = view0, b_normal = normal0;
-                        int b_mat = matid0;
-                        if (path_active) {
-                            // back from intersect() (ray_tracing.hlsl:372-395)
-                            terminate = true;
-                            if (intersected) {
-                                ray.o = pt_add3(ray.o, pt_scale3(ray.d, current_t));
-                                itr++;
-                                const float4 *shp = reinterpret_cast<const float4 *>(&sc.shade[hit_prim]);
-                                const float4 s0 = shp[0], s1 = shp[1], s2 = shp[2];
-                                bool ended = false;
-                                if (itr > MAX_ITR) {
-                                    const float pr = pt_max(pt_max(multi.x, multi.y), multi.z);
-                                    if (pr > rand_next(seed)) multi = pt_scale3(multi, 1 / pr);
-                                    else ended = true;
-                                }
-                                if (!ended && itr >= MAX_ITR * 3) ended = true;
-                                if (!ended) {
-                                    const pt_f3 A = pt_mk3(s0.x, s0.y, s0.z), B = pt_mk3(s1.x, s1.y, s1.z), C = pt_mk3(s2.x, s2.y, s2.z);
-                                    b_normal = pt_add3(pt_add3(pt_scale3(A, hit_bz), pt_scale3(B, hit_bx)), pt_scale3(C, hit_by));
-                                    b_view = ray.d;
-                                    b_mat = __float_as_int(s0.w);
-                                    bounce = true;
-                                    terminate = false;
-                                }
+                    pt_f3 direction;
+                    bool cont = false, bounce = false;
+                    pt_f3 b_view = view0, b_normal = normal0;
+                    int b_mat = matid0;
+                    if (path_active) {
+                        // back from intersect() (ray_tracing.hlsl:372-395)
+                        bool ended = true;
+                        if (intersected) {
+                            ray.o = pt_add3(ray.o, pt_scale3(ray.d, current_t));
+                            itr++;
+                            const float4 *shp = reinterpret_cast<const float4 *>(&sc.shade[hit_prim]);
+                            const float4 s0 = shp[0], s1 = shp[1], s2 = shp[2];
+                            ended = false;
+                            if (itr > MAX_ITR) {
+                                const float pr = pt_max(pt_max(multi.x, multi.y), multi.z);
+                                if (pr > rand_next(seed)) multi = pt_scale3(multi, 1 / pr);
+                                else ended = true;
                             }
-                        } else if (f < count) {
+                            if (!ended && itr >= MAX_ITR * 3) ended = true;
+                            if (!ended) {
+                                const pt_f3 A = pt_mk3(s0.x, s0.y, s0.z), B = pt_mk3(s1.x, s1.y, s1.z), C = pt_mk3(s2.x, s2.y, s2.z);
+                                b_normal = pt_add3(pt_add3(pt_scale3(A, hit_bz), pt_scale3(B, hit_bx)), pt_scale3(C, hit_by));
+                                b_view = ray.d;
+                                b_mat = __float_as_int(s0.w);
+                                bounce = true;
+                            }
+                        }
+                        if (ended) {
+                            accumulate(pt_mk3(0, 0, 0), first_frame + f);
+                            path_active = false;
+                            f++;
+                        }
+                    }
+                    if (!path_active) {
+                        if (f < count) {
                             // new path of frame f (ray_tracing.hlsl:348-370, 410)
                             cnt.paths++;
                             seed = rand_init(pixel_id, seeds[f]);
@@ -764,32 +769,32 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                             store_pixel();
                             has_px = false;
                         }
-                        if (bounce) {
-                            // one call site: lanes continuing a path and lanes starting one shade together
-                            if (get_bounce(mats, framecount, b_view, b_normal, b_mat, multi, direction, seed)) cont = true;
-                            else { color = multi; terminate = true; }
-                        }
-                        if (terminate) {
-                            accumulate(color, framecount);
+                    }
+                    if (bounce) {
+                        const uint32_t framecount = first_frame + f;
+                        if (get_bounce(mats, framecount, b_view, b_normal, b_mat, multi, direction, seed)) {
+                            cont = true;
+                        } else {
+                            accumulate(multi, framecount);
                             path_active = false;
                             f++;
                         }
-                        if (cont) {
-                            // start intersect() (ray_tracing.hlsl:191-214) with the root's own box test
-                            ray.d = direction;
-                            inv = pt_mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-                            current_t = ray.t_max;
-                            intersected = false;
-                            pending = 0;
-                            cnt.rays++;
-                            if (COUNT) { cnt.node_visits++; cnt.box_tests++; }
-                            float t_entry;
-                            if (slab(root_mn, root_mx, ray.o, inv, t_entry) && t_entry <= current_t) {
-                                cur_k = levels; cur_s = 0; cur_id = 0;
-                                have_ray = true;
-                            }
+                    }
+                    if (cont) {
+                        // start intersect() (ray_tracing.hlsl:191-214) with the root's own box test;
+                        // a ray that misses the root stays idle and is finished as a miss next round
+                        ray.d = direction;
+                        inv = pt_mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+                        current_t = ray.t_max;
+                        intersected = false;
+                        pending = 0;
+                        cnt.rays++;
+                        if (COUNT) { cnt.node_visits++; cnt.box_tests++; }
+                        float t_entry;
+                        if (slab(root_mn, root_mx, ray.o, inv, t_entry) && t_entry <= current_t) {
+                            cur_k = levels; cur_s = 0; cur_id = 0;
                         }
-                    } while (has_px && !have_ray);
+                    }
                 }
                 if (__ballot(!has_px && !exhausted) == 0) break;
             }
@@ -862,24 +867,20 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                 }
             }
             if (trav && cur_k == K_POP) {
-                // up to two pending children per iteration: entries whose entry distance no
-                // longer passes the distance test are dropped
-#pragma unroll
-                for (int attempt = 0; attempt < 2; attempt++) {
-                    if (cur_k != K_POP) break;
-                    if (pending == 0) {
-                        cur_k = K_IDLE;
-                    } else {
-                        const int L = __ffs((int)pending) - 1;          // deepest pending ancestor level
-                        pending &= pending - 1;
-                        const float t_entry = stack[(L - 1) * nthreads];
-                        if (t_entry <= current_t) {
-                            const int sa = (cur_s >> L) << L, half = 1 << (L - 1);
-                            const int sr = sa + half, e = min(sa + 2 * half - 1, n);
-                            cur_k = 32 - __clz(sr ^ e);
-                            cur_s = sr;
-                            cur_id = sr;
-                        }
+                // one pending child per iteration; an entry whose entry distance no longer passes
+                // the distance test is dropped and the lane tries again next iteration
+                if (pending == 0) {
+                    cur_k = K_IDLE;
+                } else {
+                    const int L = __ffs((int)pending) - 1;              // deepest pending ancestor level
+                    pending &= pending - 1;
+                    const float t_entry = stack[(L - 1) * nthreads];
+                    if (t_entry <= current_t) {
+                        const int sa = (cur_s >> L) << L, half = 1 << (L - 1);
+                        const int sr = sa + half, e = min(sa + 2 * half - 1, n);
+                        cur_k = 32 - __clz(sr ^ e);
+                        cur_s = sr;
+                        cur_id = sr;
                     }
                 }
             }
@@ -1066,7 +1067,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
 {
     SceneView sv;
     if (int rc = make_view(ctx, sv)) return rc;
-    Tuning tune = {24, 12};
+    Tuning tune = {16, 12};
     if (const char *e = getenv("PTAMD_REFILL_T")) tune.refill_t = atoi(e);
     if (const char *e = getenv("PTAMD_LEAF_T")) tune.leaf_t = atoi(e);
     const bool lin = (mode == PT_ACCUM_LINEAR);
