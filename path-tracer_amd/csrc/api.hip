@@ -48,6 +48,10 @@ static void free_images(pt_context *ctx)
 {
     dev_free(ctx->d_diffuse); dev_free(ctx->d_normal); dev_free(ctx->d_world);
     dev_free(ctx->d_output); dev_free(ctx->d_display); dev_free(ctx->d_linear);
+    dev_free(ctx->d_samples); ctx->samples_frames = 0;
+    dev_free(ctx->d_cost); dev_free(ctx->d_pixel_work); dev_free(ctx->d_okeys[0]); dev_free(ctx->d_okeys[1]);
+    dev_free(ctx->d_ovals[0]); dev_free(ctx->d_ovals[1]); dev_free(ctx->d_ohist); dev_free(ctx->d_ototal);
+    ctx->order_valid = false;
     ctx->W = ctx->H = 0;
     ctx->have_gbuffer = false;
 }
@@ -313,12 +317,22 @@ int pt_resize(pt_context *ctx, int width, int height)
     if (!rc) rc = dev_alloc(ctx, &ctx->d_output, npix);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_display, npix * 4);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_linear, npix);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_cost, npix);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_pixel_work, npix);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_okeys[0], npix);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_okeys[1], npix);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_ovals[0], npix);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_ovals[1], npix);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_ohist, 256 * ((npix + PT_SORT_TILE - 1) / PT_SORT_TILE));
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_ototal, 512);
     if (rc) { free_images(ctx); return rc; }
     ctx->W = width;
     ctx->H = height;
     PT_HIP(ctx, hipMemsetAsync(ctx->d_diffuse, 0, npix * 4, ctx->stream));
     PT_HIP(ctx, hipMemsetAsync(ctx->d_normal, 0, npix * 16, ctx->stream));
     PT_HIP(ctx, hipMemsetAsync(ctx->d_world, 0, npix * 16, ctx->stream));
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_cost, 0, npix * 4, ctx->stream));
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_pixel_work, 0, npix * 4, ctx->stream));
     return pt_reset_accumulation(ctx);
 }
 
@@ -347,6 +361,8 @@ int pt_upload_gbuffer(pt_context *ctx, const uint8_t *diffuse, const float *norm
     PT_HIP(ctx, hipMemcpyAsync(ctx->d_world, world, npix * 16, hipMemcpyHostToDevice, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_gbuffer = true;
+    ctx->order_valid = false;
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_cost, 0, npix * 4, ctx->stream));
     return PT_OK;
 }
 
@@ -391,7 +407,11 @@ int pt_primary_hits(pt_context *ctx, const pt_camera *cam, const uint8_t *albedo
     if (!rc) rc = ptk_primary(ctx, cam, d_alb);
     if (!rc) { e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) { ctx->err = hipGetErrorString(e); rc = PT_ERR_HIP; } }
     (void)hipFree(d_alb);
-    if (!rc) ctx->have_gbuffer = true;
+    if (!rc) {
+        ctx->have_gbuffer = true;
+        ctx->order_valid = false;
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_cost, 0, (size_t)ctx->W * ctx->H * 4, ctx->stream));
+    }
     return rc;
 }
 

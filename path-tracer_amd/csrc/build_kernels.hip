@@ -503,9 +503,48 @@ __global__ __launch_bounds__(256) void k_export_sorted(const uint32_t *__restric
     dst[1] = src[1];
 }
 
+// Folds the launch's per-pixel iteration counts into the decaying cost (window of about eight
+// launches), clears them, and makes the pixel's sort key for the trace kernel's work queue: most
+// expensive first.
+__global__ __launch_bounds__(256) void k_cost_keys(uint32_t *__restrict__ cost, uint32_t *__restrict__ pixel_work,
+                                                   int npix, int shift, uint64_t *__restrict__ keys)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const uint32_t old = cost[i];
+    const uint32_t now = old - (old >> 3) + pixel_work[i];
+    cost[i] = now;
+    pixel_work[i] = 0;
+    const uint32_t c = now >> shift;
+    keys[i] = 65535u - (c > 65535u ? 65535u : c);
+}
+
 inline int bit_length(unsigned v) { return v ? 32 - __builtin_clz(v) : 0; }
 
 }  // namespace
+
+// Orders the pixels by the work they took in earlier launches (descending, 16-bit keys, two
+// stable radix passes) so that the persistent trace kernel hands out the expensive pixels
+// first and its last wave finishes on cheap ones.  Any order gives the same image.
+int ptk_order_pixels(pt_context *ctx, int shift)
+{
+    const int npix = ctx->W * ctx->H;
+    hipStream_t st = ctx->stream;
+    const int nblocks = (npix + PT_SORT_TILE - 1) / PT_SORT_TILE;
+    hipLaunchKernelGGL(k_cost_keys, dim3((npix + 255) / 256), dim3(256), 0, st, ctx->d_cost, ctx->d_pixel_work, npix, shift, ctx->d_okeys[0]);
+    // pass 0: keys[0] -> keys[1] / vals[1] (identity values); pass 1: -> keys[0] / vals[0]
+    hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, ctx->d_okeys[0], npix, 0, ctx->d_ohist, nblocks);
+    hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, st, ctx->d_ohist, ctx->d_ototal, nblocks);
+    hipLaunchKernelGGL(k_sort_scatter<true>, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, ctx->d_okeys[0], (const uint32_t *)nullptr,
+                       ctx->d_okeys[1], ctx->d_ovals[1], npix, 0, ctx->d_ohist, ctx->d_ototal, nblocks);
+    hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, ctx->d_okeys[1], npix, 8, ctx->d_ohist, nblocks);
+    hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, st, ctx->d_ohist, ctx->d_ototal + 256, nblocks);
+    hipLaunchKernelGGL(k_sort_scatter<false>, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, ctx->d_okeys[1], ctx->d_ovals[1],
+                       ctx->d_okeys[0], ctx->d_ovals[0], npix, 8, ctx->d_ohist, ctx->d_ototal + 256, nblocks);
+    PT_HIP(ctx, hipGetLastError());
+    ctx->order_valid = true;
+    return PT_OK;
+}
 
 // ---------------------------------------------------------------------------
 // host-side sequencing

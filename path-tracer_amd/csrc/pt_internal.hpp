@@ -112,6 +112,17 @@ struct pt_context {
     uint8_t *d_display = nullptr;     // RGBA8 (`output_u`)
     float4 *d_linear = nullptr;       // linear sum, alpha = sample count
     bool have_gbuffer = false;
+    // work-queue order of the persistent trace kernel: per-pixel cost (decaying sum of the
+    // traversal iterations of earlier launches) and the pixels sorted by it
+    uint32_t *d_cost = nullptr;       // W*H
+    uint32_t *d_pixel_work = nullptr; // W*H, iterations of the current launch
+    float4 *d_samples = nullptr;      // [samples_frames][W*H] radiance samples of one launch
+    uint32_t samples_frames = 0;
+    uint64_t *d_okeys[2] = {nullptr, nullptr};
+    uint32_t *d_ovals[2] = {nullptr, nullptr};   // [0] holds the order when order_valid
+    uint32_t *d_ohist = nullptr;      // 256 * ceil(W*H / PT_SORT_TILE)
+    uint32_t *d_ototal = nullptr;     // 2 * 256
+    bool order_valid = false;
     uint32_t frame_count = 0;
     uint32_t *d_seeds = nullptr;
     std::vector<uint32_t> h_seeds;    // host staging that outlives the async copy
@@ -131,6 +142,7 @@ struct pt_context {
 int ptk_build(pt_context *ctx, unsigned flags);
 int ptk_root_box(pt_context *ctx);
 int ptk_sort_tris(pt_context *ctx);
+int ptk_order_pixels(pt_context *ctx, int shift);
 int ptk_export_sorted(pt_context *ctx, pt_PrimitiveRayCS *d_out);
 int ptk_primary(pt_context *ctx, const pt_camera *cam, const uint8_t *d_albedo);
 int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int mode);

@@ -309,15 +309,14 @@ constexpr int MAX_ITR = 5;   // ray_tracing.hlsl:245-247
 constexpr int IDLE = (int)0x80000001;      // no ray in flight
 struct Tuning { int refill_t, leaf_t; };
 
-template <bool COUNT, bool LINEAR>
+template <bool COUNT>
 __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, int H,
                                                          const uint8_t *__restrict__ diffuse_tex,
                                                          const float4 *__restrict__ normal_tex,
                                                          const float4 *__restrict__ world_tex,
                                                          uint32_t first_frame, uint32_t count,
                                                          const uint32_t *__restrict__ seeds,
-                                                         float4 *__restrict__ output, uint8_t *__restrict__ display,
-                                                         float4 *__restrict__ linear, DevCounters *__restrict__ counters,
+                                                         float4 *__restrict__ samples, DevCounters *__restrict__ counters,
                                                          Tuning tune)
 {
     extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];
@@ -331,7 +330,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, in
     const bool in_image = (x < W && y < H);
     const size_t p = in_image ? (size_t)y * (size_t)W + (size_t)x : 0;
     const pt_Material *mats = sc.cb->mats;
-    const float inv_gamma = 1 / 2.2f;
+    const size_t npix = (size_t)W * (size_t)H;
 
     // per-pixel constants of the first bounce (ray_tracing.hlsl:349-367)
     const uchar4 dif8 = reinterpret_cast<const uchar4 *>(diffuse_tex)[p];
@@ -352,23 +351,9 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, in
     const uint32_t pixel_id = (uint32_t)((float)(uint32_t)x + (float)(uint32_t)y * (float)W);
     const float root_mn[3] = {sc.root[0], sc.root[1], sc.root[2]}, root_mx[3] = {sc.root[3], sc.root[4], sc.root[5]};
 
-    float4 acc = make_float4(0, 0, 0, 0);
-    if (in_image) acc = LINEAR ? linear[p] : output[p];
-
-    auto accumulate = [&](const pt_f3 &color, uint32_t framecount) {
-        if (LINEAR) {
-            acc.x += color.x; acc.y += color.y; acc.z += color.z; acc.w += 1.0f;
-        } else {
-            // ray_tracing.hlsl:412-419
-            const float this_color[4] = {color.x, color.y, color.z, 1.0f};
-            const float old_factor = 1.0f * (float)framecount / (float)(framecount + 1);
-            const float new_factor = 1.0f / (float)(framecount + 1);
-            float o[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                o[k] = pt_powf(pt_powf(o[k], 2.2f) * old_factor + this_color[k] * new_factor, inv_gamma);
-            acc = make_float4(o[0], o[1], o[2], o[3]);
-        }
+    // the radiance sample of local frame fl (ray_tracing.hlsl:396-411: `multi` or black)
+    auto emit = [&](const pt_f3 &color, uint32_t fl) {
+        samples[(size_t)fl * npix + p] = make_float4(color.x, color.y, color.z, 1.0f);
     };
 
     // lane state
@@ -389,7 +374,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, in
 
     if (alive && background) {
         // ray_tracing.hlsl:361-362: black, but still accumulated every frame
-        for (uint32_t k = 0; k < count; k++) { cnt.paths++; accumulate(pt_mk3(0, 0, 0), first_frame + k); }
+        for (uint32_t k = 0; k < count; k++) { cnt.paths++; emit(pt_mk3(0, 0, 0), k); }
         alive = false;
     }
 
@@ -430,7 +415,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, in
                             }
                         }
                         if (!cont) {
-                            accumulate(color, framecount);
+                            emit(color, f);
                             path_active = false;
                             f++;
                         }
@@ -446,7 +431,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, in
                             cont = true;
                             path_active = true;
                         } else {
-                            accumulate(multi, framecount);
+                            emit(multi, f);
                             f++;
                         }
                     } else {
@@ -540,16 +525,6 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, in
         }
     }
 
-    if (in_image) {
-        if (LINEAR) {
-            linear[p] = acc;
-        } else {
-            output[p] = acc;
-            reinterpret_cast<uchar4 *>(display)[p] =
-                make_uchar4((unsigned char)to_unorm8(acc.x), (unsigned char)to_unorm8(acc.y),
-                            (unsigned char)to_unorm8(acc.z), (unsigned char)to_unorm8(acc.w));
-        }
-    }
     flush_counters(cnt, counters, COUNT);
 }
 
@@ -573,13 +548,15 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, in
 // its low bits cleared.  The LDS stack therefore holds only the entry distance,
 // one float per level.
 //
-// One persistent workgroup per CU; lanes take pixels from a global counter (64
-// consecutive pixels per wave request) and run all `count` frames of a pixel
-// before taking the next, so a wave never idles on a finished pixel.
+// One persistent workgroup per CU; lanes take work items from a global counter
+// (64 consecutive items per wave request).  An item is `chunk` consecutive frames
+// of one pixel; the pixels come in the order of `order` (most expensive first, from
+// the previous launches' per-pixel iteration counts), so the launch ends on cheap
+// items.  Items only decide who computes a sample, never its value.
 // ---------------------------------------------------------------------------
 constexpr int K_POP = -1, K_IDLE = -2;
 
-template <bool COUNT, bool LINEAR>
+template <bool COUNT>
 __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect *__restrict__ tri_sorted, int levels,
                                                     int W, int H,
                                                     const uint8_t *__restrict__ diffuse_tex,
@@ -587,9 +564,10 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                                                     const float4 *__restrict__ world_tex,
                                                     uint32_t first_frame, uint32_t count,
                                                     const uint32_t *__restrict__ seeds,
-                                                    float4 *__restrict__ output, uint8_t *__restrict__ display,
-                                                    float4 *__restrict__ linear, DevCounters *__restrict__ counters,
-                                                    unsigned *__restrict__ work_counter, Tuning tune)
+                                                    float4 *__restrict__ samples, DevCounters *__restrict__ counters,
+                                                    unsigned *__restrict__ work_counter,
+                                                    const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
+                                                    uint32_t chunk, Tuning tune)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds_nodes[];
     const int n = sc.n;
@@ -604,26 +582,27 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
     const int REFILL_T = tune.refill_t, LEAF_T = tune.leaf_t;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const unsigned total_px = (unsigned)W * (unsigned)H;
+    const unsigned npix = (unsigned)W * (unsigned)H;
+    const unsigned chunks = (count + chunk - 1) / chunk;     // items per pixel
+    const unsigned total_items = npix * chunks;
     const pt_Material *mats = sc.cb->mats;
     const pt_f3 g_pos = pt_mk3(sc.cb->pos.v[0], sc.cb->pos.v[1], sc.cb->pos.v[2]);
-    const float inv_gamma = 1 / 2.2f;
     const float root_mn[3] = {sc.root[0], sc.root[1], sc.root[2]}, root_mx[3] = {sc.root[3], sc.root[4], sc.root[5]};
     LaneCounters cnt;
     unsigned long long sched[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    // wave-uniform pixel queue
+    // wave-uniform item queue
     unsigned q_next = 0, q_end = 0;
     bool exhausted = false;
 
-    // per-pixel state
+    // per-item state (has_px: the lane holds an item)
     bool has_px = false;
     unsigned px = 0;
     int matid0 = 0;
     pt_f3 hit_pos = pt_mk3(0, 0, 0), multi0 = pt_mk3(0, 0, 0), view0 = pt_mk3(0, 0, 0), normal0 = pt_mk3(0, 0, 0);
     uint32_t pixel_id = 0;
-    float4 acc = make_float4(0, 0, 0, 0);
-    uint32_t f = 0;
+    uint32_t f = 0, f_end = 0;          // next local frame of the item, one past its last
+    uint32_t work = 0;                  // traversal iterations this item has occupied its lane
     // per-path / per-ray state
     bool path_active = false;
     int cur_k = K_IDLE, cur_s = 0, cur_id = 0;
@@ -639,30 +618,9 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
     int hit_prim = 0;
     float hit_bx = 0, hit_by = 0, hit_bz = 0;
 
-    auto accumulate = [&](const pt_f3 &color, uint32_t framecount) {
-        if (LINEAR) {
-            acc.x += color.x; acc.y += color.y; acc.z += color.z; acc.w += 1.0f;
-        } else {
-            // ray_tracing.hlsl:412-419
-            const float this_color[4] = {color.x, color.y, color.z, 1.0f};
-            const float old_factor = 1.0f * (float)framecount / (float)(framecount + 1);
-            const float new_factor = 1.0f / (float)(framecount + 1);
-            float o[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                o[k] = pt_powf(pt_powf(o[k], 2.2f) * old_factor + this_color[k] * new_factor, inv_gamma);
-            acc = make_float4(o[0], o[1], o[2], o[3]);
-        }
-    };
-    auto store_pixel = [&]() {
-        if (LINEAR) {
-            linear[px] = acc;
-        } else {
-            output[px] = acc;
-            reinterpret_cast<uchar4 *>(display)[px] =
-                make_uchar4((unsigned char)to_unorm8(acc.x), (unsigned char)to_unorm8(acc.y),
-                            (unsigned char)to_unorm8(acc.z), (unsigned char)to_unorm8(acc.w));
-        }
+    // the radiance sample of local frame fl (ray_tracing.hlsl:396-411: `multi` or black)
+    auto emit = [&](const pt_f3 &color, uint32_t fl) {
+        samples[(size_t)fl * npix + px] = make_float4(color.x, color.y, color.z, 1.0f);
     };
 
     for (;;) {
@@ -682,24 +640,26 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                         unsigned base = 0;
                         if (lane == 0) base = atomicAdd(work_counter, 64u);
                         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-                        if (base >= total_px) { exhausted = true; break; }
+                        if (base >= total_items) { exhausted = true; break; }
                         q_next = base;
-                        q_end = min(base + 64u, total_px);
+                        q_end = min(base + 64u, total_items);
                     }
                     const unsigned rank = (unsigned)__popcll(wm & lt_mask);
                     const unsigned avail = q_end - q_next;
                     if (want && rank < avail) {
-                        px = q_next + rank;
+                        const unsigned item = q_next + rank, slot = item / chunks;
+                        px = order ? order[slot] : slot;
+                        f = (item - slot * chunks) * chunk;
+                        f_end = min(f + chunk, count);
+                        work = 0;
                         const unsigned y = px / (unsigned)W, x = px - y * (unsigned)W;
                         const uchar4 dif8 = reinterpret_cast<const uchar4 *>(diffuse_tex)[px];
                         const float4 nrm4 = normal_tex[px];
                         const float4 pos4 = world_tex[px];
-                        acc = LINEAR ? linear[px] : output[px];
                         matid0 = __float_as_int(nrm4.w) - 1;            // asint(normal.w) - 1
                         if (matid0 < 0) {
                             // ray_tracing.hlsl:361-362: black, but still accumulated every frame
-                            for (uint32_t k = 0; k < count; k++) { cnt.paths++; accumulate(pt_mk3(0, 0, 0), first_frame + k); }
-                            store_pixel();
+                            for (uint32_t k = f; k < f_end; k++) { cnt.paths++; emit(pt_mk3(0, 0, 0), k); }
                         } else {
                             hit_pos = pt_mk3(pos4.x, pos4.y, pos4.z);
                             multi0 = pt_mk3(dif8.x / 255.0f, dif8.y / 255.0f, dif8.z / 255.0f);
@@ -708,7 +668,6 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                             normal0 = pt_normalize3(pt_mk3(nrm4.x, nrm4.y, nrm4.z));
                             // ray_tracing.hlsl:410: uint(launchIndex.x + launchIndex.y * viewportDims.x), in float
                             pixel_id = (uint32_t)((float)x + (float)y * (float)W);
-                            f = 0;
                             path_active = false;
                             cur_k = K_IDLE;
                             has_px = true;
@@ -750,13 +709,13 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                             }
                         }
                         if (ended) {
-                            accumulate(pt_mk3(0, 0, 0), first_frame + f);
+                            emit(pt_mk3(0, 0, 0), f);
                             path_active = false;
                             f++;
                         }
                     }
                     if (!path_active) {
-                        if (f < count) {
+                        if (f < f_end) {
                             // new path of frame f (ray_tracing.hlsl:348-370, 410)
                             cnt.paths++;
                             seed = rand_init(pixel_id, seeds[f]);
@@ -766,7 +725,7 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                             path_active = true;
                             bounce = true;
                         } else {
-                            store_pixel();
+                            if (work) atomicAdd(&pixel_work[px], work);
                             has_px = false;
                         }
                     }
@@ -775,7 +734,7 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                         if (get_bounce(mats, framecount, b_view, b_normal, b_mat, multi, direction, seed)) {
                             cont = true;
                         } else {
-                            accumulate(multi, framecount);
+                            emit(multi, f);
                             path_active = false;
                             f++;
                         }
@@ -811,6 +770,7 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                 sched[6] += __popcll(__ballot(has_px && cur_k == K_IDLE));             // waiting for a refill
                 sched[7] += __popcll(__ballot(!has_px));                               // no pixel (queue empty)
             }
+            work += trav ? 1u : 0u;
             if (trav && cur_k >= 1) {
                 const float4 *w = lds_nodes + 3 * cur_id;
                 const float4 w0 = w[0], w1 = w[1], w2 = w[2];
@@ -889,6 +849,45 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
     flush_counters(cnt, counters, COUNT);
     if (COUNT && lane == 0) {
         for (int k = 0; k < 8; k++) atomicAdd(&counters->sched[k], sched[k]);
+    }
+}
+
+// Folds the samples of `count` frames (layout [frame][pixel]) into the images, frame by frame
+// in order.  LITERAL: ray_tracing.hlsl:412-419 on `output` / `old` plus the UNORM8 copy;
+// LINEAR: running float sum, alpha counts samples.
+template <bool LINEAR>
+__global__ __launch_bounds__(256) void k_accumulate(const float4 *__restrict__ samples, size_t npix,
+                                                    uint32_t first_frame, uint32_t count,
+                                                    float4 *__restrict__ output, uint8_t *__restrict__ display,
+                                                    float4 *__restrict__ linear)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    float4 acc = LINEAR ? linear[p] : output[p];
+    const float inv_gamma = 1 / 2.2f;
+    for (uint32_t k = 0; k < count; k++) {
+        const float4 c = samples[(size_t)k * npix + p];
+        if (LINEAR) {
+            acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += 1.0f;
+        } else {
+            const uint32_t framecount = first_frame + k;
+            const float this_color[4] = {c.x, c.y, c.z, 1.0f};
+            const float old_factor = 1.0f * (float)framecount / (float)(framecount + 1);
+            const float new_factor = 1.0f / (float)(framecount + 1);
+            float o[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                o[j] = pt_powf(pt_powf(o[j], 2.2f) * old_factor + this_color[j] * new_factor, inv_gamma);
+            acc = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    if (LINEAR) {
+        linear[p] = acc;
+    } else {
+        output[p] = acc;
+        reinterpret_cast<uchar4 *>(display)[p] =
+            make_uchar4((unsigned char)to_unorm8(acc.x), (unsigned char)to_unorm8(acc.y),
+                        (unsigned char)to_unorm8(acc.z), (unsigned char)to_unorm8(acc.w));
     }
 }
 
@@ -1063,6 +1062,16 @@ static int lds_resident_threads(const pt_context *ctx, int *levels_out, size_t *
     return (int)t;
 }
 
+// Frames per kernel launch: the samples of one launch are staged as [frame][pixel] float4 and
+// folded into the images by k_accumulate; the staging buffer is capped at 2 GiB.
+static uint32_t frames_per_launch(const pt_context *ctx, uint32_t count)
+{
+    const size_t per_frame = (size_t)ctx->W * ctx->H * sizeof(float4);
+    size_t cap = ((size_t)2 << 30) / per_frame;
+    if (cap < 1) cap = 1;
+    return (uint32_t)(count < cap ? count : cap);
+}
+
 int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int mode)
 {
     SceneView sv;
@@ -1071,33 +1080,71 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
     if (const char *e = getenv("PTAMD_REFILL_T")) tune.refill_t = atoi(e);
     if (const char *e = getenv("PTAMD_LEAF_T")) tune.leaf_t = atoi(e);
     const bool lin = (mode == PT_ACCUM_LINEAR);
+    const size_t npix = (size_t)ctx->W * ctx->H;
     int levels = 0;
     size_t lds_bytes = 0;
     int threads = lds_resident_threads(ctx, &levels, &lds_bytes);
     if (const char *e = getenv("PTAMD_NO_LDS_TREE")) if (atoi(e)) threads = 0;
     if (const char *e = getenv("PTAMD_LDS_THREADS")) { int t = atoi(e); if (t >= 64 && t <= threads) { threads = (t / 64) * 64; lds_bytes = (size_t)ctx->n * 48 + (size_t)levels * 4 * threads; } }
-    if (threads >= 256) {
-        PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
-#define PT_LAUNCH_LDS(C, L) do { \
-        PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_lds<C, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-        hipLaunchKernelGGL((k_trace_lds<C, L>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
-            ctx->W, ctx->H, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first_frame, count, ctx->d_seeds, \
-            ctx->d_output, ctx->d_display, ctx->d_linear, ctx->d_counters, ctx->d_work, tune); } while (0)
-        if (ctx->detailed) { if (lin) PT_LAUNCH_LDS(true, true); else PT_LAUNCH_LDS(true, false); }
-        else               { if (lin) PT_LAUNCH_LDS(false, true); else PT_LAUNCH_LDS(false, false); }
-#undef PT_LAUNCH_LDS
-        PT_HIP(ctx, hipGetLastError());
-        return PT_OK;
+    static const bool no_order = getenv("PTAMD_NO_ORDER") && atoi(getenv("PTAMD_NO_ORDER"));
+
+    const uint32_t per_launch = frames_per_launch(ctx, count);
+    if (ctx->samples_frames < per_launch) {
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_samples) (void)hipFree(ctx->d_samples);
+        ctx->d_samples = nullptr;
+        ctx->samples_frames = 0;
+        PT_HIP(ctx, hipMalloc((void **)&ctx->d_samples, (size_t)per_launch * npix * sizeof(float4)));
+        ctx->samples_frames = per_launch;
     }
-    dim3 grid((ctx->W + 15) / 16, (ctx->H + 15) / 16), block(TRACE_THREADS);
-    const size_t lds = stack_bytes(ctx);
-#define PT_LAUNCH_TRACE(C, L) hipLaunchKernelGGL((k_trace<C, L>), grid, block, lds, ctx->stream, sv, ctx->W, ctx->H, \
-        ctx->d_diffuse, ctx->d_normal, ctx->d_world, first_frame, count, ctx->d_seeds, \
-        ctx->d_output, ctx->d_display, ctx->d_linear, ctx->d_counters, tune)
-    if (ctx->detailed) { if (lin) PT_LAUNCH_TRACE(true, true); else PT_LAUNCH_TRACE(true, false); }
-    else               { if (lin) PT_LAUNCH_TRACE(false, true); else PT_LAUNCH_TRACE(false, false); }
+
+    for (uint32_t off = 0; off < count; off += per_launch) {
+        const uint32_t cnt = (count - off < per_launch) ? count - off : per_launch;
+        const uint32_t first = first_frame + off;
+        const uint32_t *seeds = ctx->d_seeds + off;
+        if (threads >= 256) {
+            // frames per work item: about 16 items per lane, so that the launch ends on short
+            // items, in equal parts of the launch's frames
+            const unsigned long long lanes = (unsigned long long)ctx->num_cus * threads;
+            unsigned long long chunk = ((unsigned long long)cnt * npix) / (lanes * 16ull);
+            if (chunk < 1) chunk = 1;
+            if (chunk > cnt) chunk = cnt;
+            chunk = (cnt + (cnt + chunk - 1) / chunk - 1) / ((cnt + chunk - 1) / chunk);
+            if (const char *e = getenv("PTAMD_CHUNK")) { chunk = (unsigned long long)atoi(e); if (chunk < 1) chunk = 1; if (chunk > cnt) chunk = cnt; }
+            PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
+#define PT_LAUNCH_LDS(C) do { \
+            PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_lds<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+            hipLaunchKernelGGL((k_trace_lds<C>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
+                ctx->W, ctx->H, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, seeds, \
+                ctx->d_samples, ctx->d_counters, ctx->d_work, \
+                ctx->order_valid ? ctx->d_ovals[0] : (const uint32_t *)nullptr, ctx->d_pixel_work, (uint32_t)chunk, tune); } while (0)
+            if (ctx->detailed) PT_LAUNCH_LDS(true); else PT_LAUNCH_LDS(false);
+#undef PT_LAUNCH_LDS
+            PT_HIP(ctx, hipGetLastError());
+            // queue order of the next launch from the decaying per-pixel iteration counts (about
+            // eight launches of at most 2^12 iterations per frame), reduced to 16 bits
+            if (!no_order) {
+                const unsigned long long top = (unsigned long long)cnt << 15;
+                int bits = 0;
+                while ((top >> bits) != 0) bits++;
+                if (int rc = ptk_order_pixels(ctx, bits > 16 ? bits - 16 : 0)) return rc;
+            }
+        } else {
+            dim3 grid((ctx->W + 15) / 16, (ctx->H + 15) / 16), block(TRACE_THREADS);
+            const size_t lds = stack_bytes(ctx);
+#define PT_LAUNCH_TRACE(C) hipLaunchKernelGGL((k_trace<C>), grid, block, lds, ctx->stream, sv, ctx->W, ctx->H, \
+                ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, seeds, ctx->d_samples, ctx->d_counters, tune)
+            if (ctx->detailed) PT_LAUNCH_TRACE(true); else PT_LAUNCH_TRACE(false);
 #undef PT_LAUNCH_TRACE
-    PT_HIP(ctx, hipGetLastError());
+            PT_HIP(ctx, hipGetLastError());
+        }
+        const dim3 agrid((unsigned)((npix + 255) / 256));
+        if (lin) hipLaunchKernelGGL(k_accumulate<true>, agrid, dim3(256), 0, ctx->stream, ctx->d_samples, npix, first, cnt,
+                                    ctx->d_output, ctx->d_display, ctx->d_linear);
+        else     hipLaunchKernelGGL(k_accumulate<false>, agrid, dim3(256), 0, ctx->stream, ctx->d_samples, npix, first, cnt,
+                                    ctx->d_output, ctx->d_display, ctx->d_linear);
+        PT_HIP(ctx, hipGetLastError());
+    }
     return PT_OK;
 }
 
