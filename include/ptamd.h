@@ -158,6 +158,18 @@ int pt_output_device_ptr(pt_context *ctx, void **dev_rgba32f, void **dev_rgba8);
  * for trees deeper than 13 levels.  Allowed: 15 or 32 or 64. */
 int pt_set_stack_size(pt_context *ctx, int entries);
 
+/* how pt_trace / pt_trace_frames schedule the paths of a launch on scenes whose tree fits
+ * in LDS (larger scenes always use one kernel with the tree in global memory).  No
+ * counterpart in the reference (one Dispatch per frame, ray_tracer.cpp:281-335); the
+ * images, counters and frame counter do not depend on the choice.
+ *   PT_SCHEDULE_PERSISTENT (default): one persistent kernel; a lane runs whole paths.
+ *   PT_SCHEDULE_WAVEFRONT: first-bounce kernel, then one intersect kernel and one
+ *     shading kernel per bounce over queues of live paths (112 bytes of queue per path
+ *     of a launch). */
+#define PT_SCHEDULE_PERSISTENT 0
+#define PT_SCHEDULE_WAVEFRONT  1
+int pt_set_trace_schedule(pt_context *ctx, int schedule);
+
 typedef struct pt_counters {
     uint64_t paths;        /* pixel-frames traced                        */
     uint64_t rays;         /* intersect() calls = BVH traversals         */

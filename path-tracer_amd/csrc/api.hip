@@ -49,6 +49,7 @@ static void free_images(pt_context *ctx)
     dev_free(ctx->d_diffuse); dev_free(ctx->d_normal); dev_free(ctx->d_world);
     dev_free(ctx->d_output); dev_free(ctx->d_display); dev_free(ctx->d_linear);
     dev_free(ctx->d_samples); ctx->samples_frames = 0;
+    dev_free(ctx->d_wf_queue[0]); dev_free(ctx->d_wf_queue[1]); dev_free(ctx->d_wf_hits); ctx->wf_paths = 0;
     dev_free(ctx->d_cost); dev_free(ctx->d_pixel_work); dev_free(ctx->d_okeys[0]); dev_free(ctx->d_okeys[1]);
     dev_free(ctx->d_ovals[0]); dev_free(ctx->d_ovals[1]); dev_free(ctx->d_ohist); dev_free(ctx->d_ototal);
     ctx->order_valid = false;
@@ -97,6 +98,7 @@ int pt_create(int device_ordinal, pt_context **out)
     if (!rc) rc = dev_alloc(ctx, &ctx->d_digit_total, 8 * 256);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_counters, 1);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_work, 64);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_wf_counts, 32 * 64 * 32);
     if (!rc) { hipError_t e2 = hipMemset(ctx->d_counters, 0, sizeof(DevCounters)); if (e2 != hipSuccess) rc = PT_ERR_HIP; }
     for (int i = 0; !rc && i <= PT_STAGE_COUNT; i++) {
         hipError_t e2 = hipEventCreate(&ctx->ev[i]);
@@ -117,7 +119,7 @@ void pt_destroy(pt_context *ctx)
     free_images(ctx);
     if (ctx->prims_owned) { void *p = const_cast<pt_PrimitiveRender *>(ctx->d_prims); if (p) (void)hipFree(p); }
     dev_free(ctx->d_cb); dev_free(ctx->d_bbox_enc); dev_free(ctx->d_root); dev_free(ctx->d_digit_total);
-    dev_free(ctx->d_counters); dev_free(ctx->d_seeds); dev_free(ctx->d_work);
+    dev_free(ctx->d_counters); dev_free(ctx->d_seeds); dev_free(ctx->d_work); dev_free(ctx->d_wf_counts);
     for (int i = 0; i <= PT_STAGE_COUNT; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     delete ctx;
 }
@@ -538,6 +540,15 @@ int pt_set_stack_size(pt_context *ctx, int entries)
     if (!ctx) return PT_ERR_INVALID;
     if (entries != 0 && entries != 15 && entries != 32) PT_FAIL(ctx, PT_ERR_INVALID, "pt_set_stack_size: 0 (automatic), 15 or 32");
     ctx->stack_entries = entries;
+    return PT_OK;
+}
+
+int pt_set_trace_schedule(pt_context *ctx, int schedule)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (schedule != PT_SCHEDULE_PERSISTENT && schedule != PT_SCHEDULE_WAVEFRONT)
+        PT_FAIL(ctx, PT_ERR_INVALID, "pt_set_trace_schedule: PT_SCHEDULE_PERSISTENT or PT_SCHEDULE_WAVEFRONT");
+    ctx->schedule = schedule;
     return PT_OK;
 }
 

@@ -118,6 +118,11 @@ struct pt_context {
     uint32_t *d_pixel_work = nullptr; // W*H, iterations of the current launch
     float4 *d_samples = nullptr;      // [samples_frames][W*H] radiance samples of one launch
     uint32_t samples_frames = 0;
+    // wavefront trace: two path queues (48-byte records), hit records (16 bytes), queue lengths
+    void *d_wf_queue[2] = {nullptr, nullptr};
+    void *d_wf_hits = nullptr;
+    size_t wf_paths = 0;              // paths the three buffers above were sized for
+    unsigned *d_wf_counts = nullptr;  // 32 x 64 counters, 128 bytes apart
     uint64_t *d_okeys[2] = {nullptr, nullptr};
     uint32_t *d_ovals[2] = {nullptr, nullptr};   // [0] holds the order when order_valid
     uint32_t *d_ohist = nullptr;      // 256 * ceil(W*H / PT_SORT_TILE)
@@ -130,6 +135,7 @@ struct pt_context {
 
     // options / counters
     int stack_entries = 0;            // 0 = automatic
+    int schedule = 0;                 // PT_SCHEDULE_*
     bool detailed = false;
     DevCounters *d_counters = nullptr;
 };

@@ -18,7 +18,9 @@
 // pending right children (id + entry distance) on a per-lane LDS stack.
 #include "pt_internal.hpp"
 
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 namespace {
 
@@ -772,7 +774,7 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
             }
             work += trav ? 1u : 0u;
             if (trav && cur_k >= 1) {
-                const float4 *w = lds_nodes + 3 * cur_id;
+                const float4 *w = lds_nodes + __umul24((unsigned)cur_id, 3u);   // 24-bit multiply: full rate
                 const float4 w0 = w[0], w1 = w[1], w2 = w[2];
                 const float lmn[3] = {w0.x, w0.y, w0.z}, lmx[3] = {w0.w, w1.x, w1.y};
                 const float rmn[3] = {w1.z, w1.w, w2.x}, rmx[3] = {w2.y, w2.z, w2.w};
@@ -782,7 +784,7 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                 if (COUNT) { cnt.node_visits += 2; cnt.box_tests += 2; }
                 const int k = cur_k, half = 1 << (k - 1);
                 if (hl) {
-                    if (hr) { stack[(k - 1) * nthreads] = tr; pending |= 1u << k; }
+                    if (hr) { stack[__umul24((unsigned)(k - 1), (unsigned)nthreads)] = tr; pending |= 1u << k; }
                     cur_k = k - 1;
                     cur_id = cur_s + half - 1;
                 } else if (hr) {
@@ -834,7 +836,7 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                 } else {
                     const int L = __ffs((int)pending) - 1;              // deepest pending ancestor level
                     pending &= pending - 1;
-                    const float t_entry = stack[(L - 1) * nthreads];
+                    const float t_entry = stack[__umul24((unsigned)(L - 1), (unsigned)nthreads)];
                     if (t_entry <= current_t) {
                         const int sa = (cur_s >> L) << L, half = 1 << (L - 1);
                         const int sr = sa + half, e = min(sa + 2 * half - 1, n);
@@ -850,6 +852,368 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
     if (COUNT && lane == 0) {
         for (int k = 0; k < 8; k++) atomicAdd(&counters->sched[k], sched[k]);
     }
+}
+
+// ---------------------------------------------------------------------------
+// Wavefront form of ray_tracing.hlsl:348-397 for scenes whose tree fits in LDS.
+//
+// In the single-kernel form a wave pays for the whole shading code (material
+// sampling with its sine, cosine, power and square roots, path start with the
+// 16-round seed hash) every time a quarter of its lanes finish a ray.  Here the
+// paths of one launch are advanced bounce by bounce instead:
+//   k_wf_first  : one thread per (frame, pixel): the first bounce off the G-buffer
+//                 (ray_tracing.hlsl:348-370); continuing paths are appended to a queue;
+//   k_wf_extend : intersect() (ray_tracing.hlsl:191-243) for every queued path, by
+//                 persistent workgroups with the tree in LDS; writes one hit record
+//                 per path.  A lane that finishes takes the next queued ray, which
+//                 costs a 32-byte load and the root test, not a shading pass;
+//   k_wf_shade  : one thread per queued path: the loop body of second_tracing
+//                 (ray_tracing.hlsl:372-395); continuing paths go to the next queue.
+// A path is at most 14 rays long (itr reaches MAX_ITR * 3), so a launch is the
+// first-bounce kernel plus 14 extend / shade pairs; queue lengths stay on the
+// device.  A path's state (origin, direction, throughput, seed, bounce count)
+// travels in its 48-byte queue record, so every kernel reads and writes
+// consecutive records.  Per path the sequence of random draws, tests and
+// arithmetic is that of the sequential loop; which thread runs it does not
+// enter the result.
+//
+// Queues are split into WF_SEGS segments of `seg_size` records.  The survivors of
+// the inputs of segment k are appended to segment k of the next queue (they
+// cannot outnumber the inputs), so every queue counter -- append positions and
+// the extend kernel's read heads -- exists once per segment, each in its own
+// 128-byte line: atomics on one address retire one at a time (about 13 ns each
+// here), and a single counter per queue would cost more than the tracing.
+// ---------------------------------------------------------------------------
+constexpr int WF_SEGS = 64;             // = lanes of a wave: one lane inspects one segment
+constexpr int WF_CSTRIDE = 32;          // words between counters (128 bytes)
+struct PathRec {                 // 48 bytes
+    float ox, oy, oz; uint32_t seed;
+    float dx, dy, dz; uint32_t slot;      // slot = local frame * pixels + pixel: the sample to write
+    float mx, my, mz; int itr;
+};
+struct HitRec { float t; int prim; float bx, by; };   // prim < 0: no hit
+
+constexpr int WF_MAX_RAYS = MAX_ITR * 3 - 1;           // rays of the longest path
+
+// appends the records of the lanes with `keep` to queue[*count ...] (one atomic per wave)
+__device__ __forceinline__ void wf_append(bool keep, const PathRec &rec, PathRec *__restrict__ queue,
+                                          unsigned *__restrict__ count)
+{
+    const unsigned long long m = __ballot(keep);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    unsigned base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(count, (unsigned)__popcll(m));
+    base = (unsigned)__shfl((int)base, __ffsll((long long)m) - 1, 64);
+    if (keep) {
+        float4 *dst = reinterpret_cast<float4 *>(&queue[base + (unsigned)__popcll(m & lt)]);
+        dst[0] = make_float4(rec.ox, rec.oy, rec.oz, __uint_as_float(rec.seed));
+        dst[1] = make_float4(rec.dx, rec.dy, rec.dz, __uint_as_float(rec.slot));
+        dst[2] = make_float4(rec.mx, rec.my, rec.mz, __int_as_float(rec.itr));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wf_first(SceneView sc, int W, int H,
+                                                  const uint8_t *__restrict__ diffuse_tex,
+                                                  const float4 *__restrict__ normal_tex,
+                                                  const float4 *__restrict__ world_tex,
+                                                  uint32_t first_frame, uint32_t count,
+                                                  const uint32_t *__restrict__ seeds,
+                                                  float4 *__restrict__ samples,
+                                                  PathRec *__restrict__ queue, unsigned *__restrict__ qcount,
+                                                  unsigned seg_size, DevCounters *__restrict__ counters)
+{
+    const unsigned npix = (unsigned)W * (unsigned)H;
+    const unsigned total = npix * count;
+    const pt_Material *mats = sc.cb->mats;
+    const pt_f3 g_pos = pt_mk3(sc.cb->pos.v[0], sc.cb->pos.v[1], sc.cb->pos.v[2]);
+    LaneCounters cnt;
+    // whole waves iterate together so that wf_append sees every lane
+    for (unsigned base = blockIdx.x * 256u; base < total; base += gridDim.x * 256u) {
+        const unsigned slot = base + threadIdx.x;
+        bool cont = false;
+        PathRec rec = {};
+        if (slot < total) {
+            const unsigned fl = slot / npix, px = slot - fl * npix;
+            const float4 nrm4 = normal_tex[px];
+            const int matid0 = __float_as_int(nrm4.w) - 1;              // asint(normal.w) - 1
+            cnt.paths++;
+            pt_f3 color = pt_mk3(0, 0, 0);                              // ray_tracing.hlsl:361-362
+            if (matid0 >= 0) {
+                const unsigned y = px / (unsigned)W, x = px - y * (unsigned)W;
+                const uchar4 dif8 = reinterpret_cast<const uchar4 *>(diffuse_tex)[px];
+                const float4 pos4 = world_tex[px];
+                const pt_f3 hit_pos = pt_mk3(pos4.x, pos4.y, pos4.z);
+                pt_f3 multi = pt_mk3(dif8.x / 255.0f, dif8.y / 255.0f, dif8.z / 255.0f);
+                if (mats[matid0].ns > 1) multi = pt_mk3(1, 1, 1);
+                const pt_f3 view0 = pt_normalize3(pt_sub3(hit_pos, g_pos));
+                const pt_f3 normal0 = pt_normalize3(pt_mk3(nrm4.x, nrm4.y, nrm4.z));
+                // ray_tracing.hlsl:410: uint(launchIndex.x + launchIndex.y * viewportDims.x), in float
+                const uint32_t pixel_id = (uint32_t)((float)x + (float)y * (float)W);
+                uint32_t seed = rand_init(pixel_id, seeds[fl]);
+                pt_f3 direction;
+                if (get_bounce(mats, first_frame + fl, view0, normal0, matid0, multi, direction, seed)) {
+                    cont = true;
+                    rec.ox = hit_pos.x; rec.oy = hit_pos.y; rec.oz = hit_pos.z; rec.seed = seed;
+                    rec.dx = direction.x; rec.dy = direction.y; rec.dz = direction.z; rec.slot = slot;
+                    rec.mx = multi.x; rec.my = multi.y; rec.mz = multi.z; rec.itr = 1;
+                } else {
+                    color = multi;
+                }
+            }
+            if (!cont) samples[slot] = make_float4(color.x, color.y, color.z, 1.0f);
+        }
+        const unsigned seg = base / seg_size;          // seg_size is a multiple of the block size
+        wf_append(cont, rec, queue + (size_t)seg * seg_size, qcount + seg * WF_CSTRIDE);
+    }
+    flush_counters(cnt, counters, false);
+}
+
+__global__ __launch_bounds__(256) void k_wf_shade(SceneView sc, const PathRec *__restrict__ queue_in,
+                                                  const HitRec *__restrict__ hits,
+                                                  const unsigned *__restrict__ count_in,
+                                                  PathRec *__restrict__ queue_out, unsigned *__restrict__ count_out,
+                                                  unsigned seg_size,
+                                                  float4 *__restrict__ samples, uint32_t first_frame, unsigned npix)
+{
+    // blockIdx.y = segment; the blocks of a segment stride over its records
+    const unsigned seg = blockIdx.y;
+    const unsigned total = count_in[seg * WF_CSTRIDE];
+    const size_t seg_base = (size_t)seg * seg_size;
+    const pt_Material *mats = sc.cb->mats;
+    for (unsigned base = blockIdx.x * 256u; base < total; base += gridDim.x * 256u) {
+        const unsigned i = base + threadIdx.x;
+        bool cont = false;
+        PathRec rec = {};
+        if (i < total) {
+            const float4 *src = reinterpret_cast<const float4 *>(&queue_in[seg_base + i]);
+            const float4 r0 = src[0], r1 = src[1], r2 = src[2];
+            const float4 h = reinterpret_cast<const float4 *>(hits)[seg_base + i];
+            const int prim = __float_as_int(h.y);
+            const uint32_t slot = __float_as_uint(r1.w);
+            uint32_t seed = __float_as_uint(r0.w);
+            pt_f3 multi = pt_mk3(r2.x, r2.y, r2.z);
+            int itr = __float_as_int(r2.w);
+            pt_f3 color = pt_mk3(0, 0, 0);
+            if (prim >= 0) {
+                // back from intersect() with a hit (ray_tracing.hlsl:372-395)
+                const pt_f3 d = pt_mk3(r1.x, r1.y, r1.z);
+                const pt_f3 o = pt_add3(pt_mk3(r0.x, r0.y, r0.z), pt_scale3(d, h.x));
+                itr++;
+                bool ended = false;
+                if (itr > MAX_ITR) {
+                    const float pr = pt_max(pt_max(multi.x, multi.y), multi.z);
+                    if (pr > rand_next(seed)) multi = pt_scale3(multi, 1 / pr);
+                    else ended = true;
+                }
+                if (!ended && itr >= MAX_ITR * 3) ended = true;
+                if (!ended) {
+                    const float4 *shp = reinterpret_cast<const float4 *>(&sc.shade[prim]);
+                    const float4 s0 = shp[0], s1 = shp[1], s2 = shp[2];
+                    const float bx = h.z, by = h.w, bz = 1 - bx - by;
+                    const pt_f3 A = pt_mk3(s0.x, s0.y, s0.z), B = pt_mk3(s1.x, s1.y, s1.z), C = pt_mk3(s2.x, s2.y, s2.z);
+                    const pt_f3 normal = pt_add3(pt_add3(pt_scale3(A, bz), pt_scale3(B, bx)), pt_scale3(C, by));
+                    const uint32_t framecount = first_frame + slot / npix;
+                    pt_f3 direction;
+                    if (get_bounce(mats, framecount, d, normal, __float_as_int(s0.w), multi, direction, seed)) {
+                        cont = true;
+                        rec.ox = o.x; rec.oy = o.y; rec.oz = o.z; rec.seed = seed;
+                        rec.dx = direction.x; rec.dy = direction.y; rec.dz = direction.z; rec.slot = slot;
+                        rec.mx = multi.x; rec.my = multi.y; rec.mz = multi.z; rec.itr = itr;
+                    } else {
+                        color = multi;
+                    }
+                }
+            }
+            if (!cont) samples[slot] = make_float4(color.x, color.y, color.z, 1.0f);
+        }
+        wf_append(cont, rec, queue_out + seg_base, count_out + seg * WF_CSTRIDE);
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect *__restrict__ tri_sorted, int levels,
+                                                    const PathRec *__restrict__ queue,
+                                                    const unsigned *__restrict__ count_in, unsigned seg_size,
+                                                    HitRec *__restrict__ hits, unsigned *__restrict__ heads,
+                                                    DevCounters *__restrict__ counters, Tuning tune)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 lds_nodes[];
+    const int lane = threadIdx.x & 63;
+    // lane k looks at segment k; an empty queue ends the launch before the tree is loaded
+    const unsigned my_seg_count = count_in[lane * WF_CSTRIDE];
+    if (__ballot(my_seg_count != 0) == 0) return;
+    const int n = sc.n;
+    const int nthreads = blockDim.x;
+    float *stack = reinterpret_cast<float *>(lds_nodes + 3 * n) + threadIdx.x;   // level L at stack[(L-1) * nthreads]
+    for (int i = threadIdx.x; i < 3 * n; i += nthreads) {
+        const int node = i / 3, part = i - 3 * node;
+        lds_nodes[i] = reinterpret_cast<const float4 *>(&sc.wide[node])[part];
+    }
+    __syncthreads();
+
+    const int REFILL_T = tune.refill_t, LEAF_T = tune.leaf_t;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const float root_mn[3] = {sc.root[0], sc.root[1], sc.root[2]}, root_mx[3] = {sc.root[3], sc.root[4], sc.root[5]};
+    LaneCounters cnt;
+
+    // wave-uniform: the segment this wave reads from and its current share of it (record indices)
+    int seg = (int)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % WF_SEGS);
+    unsigned q_next = 0, q_end = 0;
+    bool exhausted = false;
+    bool have = false;                     // a finished ray whose hit record is not written yet
+    unsigned ridx = 0;
+    int cur_k = K_IDLE, cur_s = 0, cur_id = 0;
+    unsigned pending = 0;
+    Ray ray;
+    ray.o = pt_mk3(0, 0, 0); ray.d = pt_mk3(0, 0, 1); ray.t_min = PT_EPSILON; ray.t_max = 10000;
+    pt_f3 inv = pt_mk3(1, 1, 1);
+    float current_t = 0;
+    int hit_prim = -1;
+    float hit_bx = 0, hit_by = 0;
+
+    for (;;) {
+        // ------------------------------------------------------------ refill
+        const bool need = cur_k == K_IDLE && (have || !exhausted);
+        const unsigned long long need_mask = __ballot(need);
+        const unsigned long long trav_mask = __ballot(cur_k >= K_POP);
+        if (need_mask == 0 && trav_mask == 0) break;
+        if (need_mask != 0 && (__popcll(need_mask) >= REFILL_T || trav_mask == 0)) {
+            if (cur_k == K_IDLE && have) {
+                reinterpret_cast<float4 *>(hits)[ridx] =
+                    make_float4(current_t, __int_as_float(hit_prim), hit_bx, hit_by);
+                have = false;
+            }
+            bool want = cur_k == K_IDLE && !exhausted;
+            unsigned long long wm = __ballot(want);
+            while (wm != 0) {
+                if (q_next == q_end) {
+                    // 64 records of the current segment; when it has none left, move to the next
+                    // segment (cyclically) that still shows unread records
+                    for (;;) {
+                        unsigned base = 0;
+                        if (lane == 0) base = atomicAdd(&heads[seg * WF_CSTRIDE], 64u);
+                        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                        const unsigned seg_total = (unsigned)__shfl((int)my_seg_count, seg, 64);
+                        if (base < seg_total) {
+                            q_next = (unsigned)seg * seg_size + base;
+                            q_end = (unsigned)seg * seg_size + min(base + 64u, seg_total);
+                            break;
+                        }
+                        const unsigned h = __hip_atomic_load(&heads[lane * WF_CSTRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long open = __ballot(h < my_seg_count);
+                        if (open == 0) { exhausted = true; break; }
+                        const unsigned long long above = (seg == 63) ? 0ull : (open & (~0ull << (seg + 1)));
+                        seg = __ffsll((long long)(above ? above : open)) - 1;
+                    }
+                    if (exhausted) break;
+                }
+                const unsigned rank = (unsigned)__popcll(wm & lt_mask);
+                const unsigned avail = q_end - q_next;
+                if (want && rank < avail) {
+                    ridx = q_next + rank;
+                    const float4 *src = reinterpret_cast<const float4 *>(&queue[ridx]);
+                    const float4 r0 = src[0], r1 = src[1];
+                    // start intersect() (ray_tracing.hlsl:191-214) with the root's own box test
+                    ray.o = pt_mk3(r0.x, r0.y, r0.z);
+                    ray.d = pt_mk3(r1.x, r1.y, r1.z);
+                    inv = pt_mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+                    current_t = ray.t_max;
+                    hit_prim = -1;
+                    pending = 0;
+                    have = true;
+                    cnt.rays++;
+                    if (COUNT) { cnt.node_visits++; cnt.box_tests++; }
+                    float t_entry;
+                    if (slab(root_mn, root_mx, ray.o, inv, t_entry) && t_entry <= current_t) {
+                        cur_k = levels; cur_s = 0; cur_id = 0;
+                    }
+                    want = false;
+                }
+                q_next += min((unsigned)__popcll(wm), avail);
+                wm = __ballot(want);
+            }
+        }
+        // --------------------------------------------------------- traversal
+        for (;;) {
+            const bool trav = cur_k >= K_POP;
+            if (__ballot(trav) == 0) break;
+            if (__popcll(__ballot(cur_k == K_IDLE && (have || !exhausted))) >= REFILL_T) break;
+            if (trav && cur_k >= 1) {
+                const float4 *w = lds_nodes + __umul24((unsigned)cur_id, 3u);   // 24-bit multiply: full rate
+                const float4 w0 = w[0], w1 = w[1], w2 = w[2];
+                const float lmn[3] = {w0.x, w0.y, w0.z}, lmx[3] = {w0.w, w1.x, w1.y};
+                const float rmn[3] = {w1.z, w1.w, w2.x}, rmx[3] = {w2.y, w2.z, w2.w};
+                float tl, tr;
+                const bool hl = slab(lmn, lmx, ray.o, inv, tl) && tl <= current_t;
+                const bool hr = slab(rmn, rmx, ray.o, inv, tr) && tr <= current_t;
+                if (COUNT) { cnt.node_visits += 2; cnt.box_tests += 2; }
+                const int k = cur_k, half = 1 << (k - 1);
+                if (hl) {
+                    if (hr) { stack[__umul24((unsigned)(k - 1), (unsigned)nthreads)] = tr; pending |= 1u << k; }
+                    cur_k = k - 1;
+                    cur_id = cur_s + half - 1;
+                } else if (hr) {
+                    const int sr = cur_s + half, e = min(cur_s + 2 * half - 1, n);
+                    cur_k = 32 - __clz(sr ^ e);
+                    cur_s = sr;
+                    cur_id = sr;
+                } else {
+                    cur_k = K_POP;
+                }
+            }
+            const bool at_leaf = trav && cur_k == 0;
+            const unsigned long long leaf_mask = __ballot(at_leaf);
+            if (leaf_mask != 0 && (__popcll(leaf_mask) >= LEAF_T || __ballot(trav && cur_k >= 1) == 0)) {
+                if (at_leaf) {
+                    const float4 *tp = reinterpret_cast<const float4 *>(&tri_sorted[cur_s]);
+                    const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    if (COUNT) cnt.tri_tests++;
+                    // ray_tracing.hlsl:167-189
+                    const pt_f3 a = pt_mk3(t0.x, t0.y, t0.z), e_1 = pt_mk3(t1.x, t1.y, t1.z), e_2 = pt_mk3(t2.x, t2.y, t2.z);
+                    const pt_f3 q = pt_cross3(ray.d, e_2);
+                    const float a1 = pt_dot3(e_1, q);
+                    if (!(fabsf(a1) <= PT_EPSILON)) {
+                        const pt_f3 oa = pt_sub3(ray.o, a);
+                        const pt_f3 s = pt_mk3(oa.x / a1, oa.y / a1, oa.z / a1);
+                        const pt_f3 r = pt_cross3(s, e_1);
+                        const float t = pt_dot3(e_2, r);
+                        const float bx = pt_dot3(s, q);
+                        const float by = pt_dot3(r, ray.d);
+                        const float bz = 1 - bx - by;
+                        if (bx >= -PT_EPSILON && by >= -PT_EPSILON && bz >= -PT_EPSILON && t >= PT_EPSILON) {
+                            if (current_t > t && t > ray.t_min) {
+                                hit_bx = bx; hit_by = by;
+                                current_t = t;
+                                hit_prim = __float_as_int(t0.w);
+                            }
+                        }
+                    }
+                    cur_k = K_POP;
+                }
+            }
+            if (trav && cur_k == K_POP) {
+                // one pending child per iteration; an entry whose entry distance no longer passes
+                // the distance test is dropped and the lane tries again next iteration
+                if (pending == 0) {
+                    cur_k = K_IDLE;
+                } else {
+                    const int L = __ffs((int)pending) - 1;              // deepest pending ancestor level
+                    pending &= pending - 1;
+                    const float t_entry = stack[__umul24((unsigned)(L - 1), (unsigned)nthreads)];
+                    if (t_entry <= current_t) {
+                        const int sa = (cur_s >> L) << L, half = 1 << (L - 1);
+                        const int sr = sa + half, e = min(sa + 2 * half - 1, n);
+                        cur_k = 32 - __clz(sr ^ e);
+                        cur_s = sr;
+                        cur_id = sr;
+                    }
+                }
+            }
+        }
+    }
+    flush_counters(cnt, counters, COUNT);
 }
 
 // Folds the samples of `count` frames (layout [frame][pixel]) into the images, frame by frame
@@ -1063,11 +1427,12 @@ static int lds_resident_threads(const pt_context *ctx, int *levels_out, size_t *
 }
 
 // Frames per kernel launch: the samples of one launch are staged as [frame][pixel] float4 and
-// folded into the images by k_accumulate; the staging buffer is capped at 2 GiB.
+// folded into the images by k_accumulate; the staging buffer is capped at 1 GiB (2^26 paths
+// per launch; the wavefront queues take another 112 bytes per path).
 static uint32_t frames_per_launch(const pt_context *ctx, uint32_t count)
 {
     const size_t per_frame = (size_t)ctx->W * ctx->H * sizeof(float4);
-    size_t cap = ((size_t)2 << 30) / per_frame;
+    size_t cap = ((size_t)1 << 30) / per_frame;
     if (cap < 1) cap = 1;
     return (uint32_t)(count < cap ? count : cap);
 }
@@ -1097,12 +1462,68 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
         PT_HIP(ctx, hipMalloc((void **)&ctx->d_samples, (size_t)per_launch * npix * sizeof(float4)));
         ctx->samples_frames = per_launch;
     }
+    bool wavefront = threads >= 256 && ctx->schedule == PT_SCHEDULE_WAVEFRONT;
+    if (const char *e = getenv("PTAMD_MEGAKERNEL")) wavefront = threads >= 256 && !atoi(e);   // A/B runs
+    if (wavefront && ctx->wf_paths < (size_t)per_launch * npix) {
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < 2; k++) { if (ctx->d_wf_queue[k]) (void)hipFree(ctx->d_wf_queue[k]); ctx->d_wf_queue[k] = nullptr; }
+        if (ctx->d_wf_hits) (void)hipFree(ctx->d_wf_hits);
+        ctx->d_wf_hits = nullptr;
+        ctx->wf_paths = 0;
+        const size_t paths = (size_t)per_launch * npix;
+        const size_t recs = paths + (size_t)WF_SEGS * 256;      // segments are rounded up to whole workgroups
+        PT_HIP(ctx, hipMalloc((void **)&ctx->d_wf_queue[0], recs * sizeof(PathRec)));
+        PT_HIP(ctx, hipMalloc((void **)&ctx->d_wf_queue[1], recs * sizeof(PathRec)));
+        PT_HIP(ctx, hipMalloc((void **)&ctx->d_wf_hits, recs * sizeof(HitRec)));
+        ctx->wf_paths = paths;
+    }
 
     for (uint32_t off = 0; off < count; off += per_launch) {
         const uint32_t cnt = (count - off < per_launch) ? count - off : per_launch;
         const uint32_t first = first_frame + off;
         const uint32_t *seeds = ctx->d_seeds + off;
-        if (threads >= 256) {
+        if (wavefront) {
+            // per depth and segment: queue length and the extend kernel's read head
+            const size_t per_depth = (size_t)WF_SEGS * WF_CSTRIDE;
+            unsigned *qcount = ctx->d_wf_counts, *qhead = ctx->d_wf_counts + 16 * per_depth;
+            PT_HIP(ctx, hipMemsetAsync(ctx->d_wf_counts, 0, 32 * per_depth * sizeof(unsigned), ctx->stream));
+            // segment size: the launch's paths in WF_SEGS equal parts, whole workgroups of the first kernel
+            const unsigned seg_size = (unsigned)(((((size_t)cnt * npix + WF_SEGS - 1) / WF_SEGS + 255) / 256) * 256);
+            PathRec *queue[2] = {static_cast<PathRec *>(ctx->d_wf_queue[0]), static_cast<PathRec *>(ctx->d_wf_queue[1])};
+            HitRec *hits = static_cast<HitRec *>(ctx->d_wf_hits);
+            const dim3 fgrid((unsigned)ctx->num_cus * 8u), sgrid(32, WF_SEGS);
+            Tuning wt = {16, 12};
+            if (const char *e = getenv("PTAMD_WF_REFILL_T")) wt.refill_t = atoi(e);
+            if (const char *e = getenv("PTAMD_WF_LEAF_T")) wt.leaf_t = atoi(e);
+            hipLaunchKernelGGL(k_wf_first, fgrid, dim3(256), 0, ctx->stream, sv, ctx->W, ctx->H, ctx->d_diffuse, ctx->d_normal,
+                               ctx->d_world, first, cnt, seeds, ctx->d_samples, queue[0], qcount + per_depth, seg_size, ctx->d_counters);
+            PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_extend<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_extend<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            for (int d = 1; d <= WF_MAX_RAYS; d++) {
+                PathRec *qin = queue[(d - 1) & 1], *qout = queue[d & 1];
+                if (ctx->detailed)
+                    hipLaunchKernelGGL((k_wf_extend<true>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted,
+                                       levels, qin, qcount + d * per_depth, seg_size, hits, qhead + d * per_depth, ctx->d_counters, wt);
+                else
+                    hipLaunchKernelGGL((k_wf_extend<false>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted,
+                                       levels, qin, qcount + d * per_depth, seg_size, hits, qhead + d * per_depth, ctx->d_counters, wt);
+                hipLaunchKernelGGL(k_wf_shade, sgrid, dim3(256), 0, ctx->stream, sv, qin, hits, qcount + d * per_depth, qout,
+                                   qcount + (d + 1) * per_depth, seg_size, ctx->d_samples, first, (unsigned)npix);
+            }
+            PT_HIP(ctx, hipGetLastError());
+            if (getenv("PTAMD_PRINT_WF")) {      // diagnostics: queue length per depth
+                std::vector<unsigned> h(32 * per_depth);
+                PT_HIP(ctx, hipMemcpyAsync(h.data(), ctx->d_wf_counts, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+                PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                fprintf(stderr, "wf queue lengths:");
+                for (int d = 1; d <= WF_MAX_RAYS + 1; d++) {
+                    unsigned long long t = 0;
+                    for (int k = 0; k < WF_SEGS; k++) t += h[d * per_depth + (size_t)k * WF_CSTRIDE];
+                    fprintf(stderr, " %llu", t);
+                }
+                fprintf(stderr, "\n");
+            }
+        } else if (threads >= 256) {
             // frames per work item: about 16 items per lane, so that the launch ends on short
             // items, in equal parts of the launch's frames
             const unsigned long long lanes = (unsigned long long)ctx->num_cus * threads;

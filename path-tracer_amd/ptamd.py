@@ -29,6 +29,8 @@ PT_BUILD_NO_TREE_EXPORT = 2
 PT_BUILD_KARRAS_LINKS = 4
 PT_ACCUM_LITERAL = 0
 PT_ACCUM_LINEAR = 1
+PT_SCHEDULE_PERSISTENT = 0
+PT_SCHEDULE_WAVEFRONT = 1
 STAGES = ("bounds", "morton", "sort", "topology", "refit", "pack")
 
 # every symbol include/ptamd.h declares
@@ -42,7 +44,7 @@ EXPORTS = (
     "pt_trace", "pt_trace_frames", "pt_frame_seeds", "pt_get_frame_count", "pt_reset_accumulation",
     "pt_linear_sum_device_ptr", "pt_resolve",
     "pt_download_output", "pt_download_display", "pt_output_device_ptr",
-    "pt_set_stack_size", "pt_set_detailed_counters", "pt_get_counters", "pt_reset_counters", "pt_intersect",
+    "pt_set_stack_size", "pt_set_trace_schedule", "pt_set_detailed_counters", "pt_get_counters", "pt_reset_counters", "pt_intersect",
 )
 
 
@@ -278,6 +280,9 @@ class Context:
     # -- options / counters -------------------------------------------------
     def set_stack_size(self, entries):
         self._ck(self.L.pt_set_stack_size(self.h, C.c_int(entries)))
+
+    def set_trace_schedule(self, schedule):
+        self._ck(self.L.pt_set_trace_schedule(self.h, C.c_int(schedule)))
 
     def set_detailed_counters(self, on):
         self._ck(self.L.pt_set_detailed_counters(self.h, C.c_int(1 if on else 0)))

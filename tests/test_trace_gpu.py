@@ -45,12 +45,18 @@ def test_gbuffer_bit_exact(gpu_ctx_factory, golden, scene):
                           kd_override=[list(m[0:3]) for m in golden[scene]["mat_table"]] + [[0, 0, 0]] * (16 - len(golden[scene]["mat_table"]))))
 
 
+SCHEDULES = [ptamd.PT_SCHEDULE_PERSISTENT, ptamd.PT_SCHEDULE_WAVEFRONT]
+
+
+@pytest.mark.parametrize("schedule", SCHEDULES)
 @pytest.mark.parametrize("scene", SCENES)
-def test_frames_bit_exact_literal(gpu_ctx_factory, golden, scene):
+def test_frames_bit_exact_literal(gpu_ctx_factory, golden, scene, schedule):
     """pt_trace one frame at a time (the reference's run loop), then a multi-frame launch that
-    must continue the same recurrence; images, display bytes and counters equal the oracle's."""
+    must continue the same recurrence; images, display bytes and counters equal the oracle's,
+    whichever way the launch schedules its paths."""
     W, H = 160, 136
     ctx = gpu_ctx_factory()
+    ctx.set_trace_schedule(schedule)
     sc, gb, _ = _setup(ctx, golden[scene], W, H)
     ctx.set_detailed_counters(True)
     seeds = ptamd.frame_seeds(1, 0, 7)
@@ -75,12 +81,14 @@ def test_frames_bit_exact_literal(gpu_ctx_factory, golden, scene):
     assert tot["rays"] > tot["paths"] and tot["tri_tests"] > 0
 
 
+@pytest.mark.parametrize("schedule", SCHEDULES)
 @pytest.mark.parametrize("scene", ["scene01", "scene04"])
-def test_frames_bit_exact_linear_and_late_frames(gpu_ctx_factory, golden, scene):
+def test_frames_bit_exact_linear_and_late_frames(gpu_ctx_factory, golden, scene, schedule):
     """Linear-sum mode, starting at a late frame index so that all stratification bits of
     framecount (ray_tracing.hlsl:306-307,325-326) are exercised."""
     W, H, first, N = 120, 104, 1000, 34
     ctx = gpu_ctx_factory()
+    ctx.set_trace_schedule(schedule)
     sc, gb, _ = _setup(ctx, golden[scene], W, H)
     seeds = ptamd.frame_seeds(1, first, N)
     ctx.trace_frames(first, seeds, ptamd.PT_ACCUM_LINEAR)
@@ -216,8 +224,8 @@ def test_full_size_frames_bit_exact(gpu_ctx_factory, golden, scene):
 
 
 def test_full_size_many_frames_properties(gpu_ctx_factory, golden):
-    """scene04, 1162x1008, 256 frames: the same frames as one launch, as eight launches and in
-    literal vs linear mode; linear alpha counts the samples; modes agree to the documented tolerance."""
+    """scene04, 1162x1008, 256 frames: the same frames as one launch, as eight launches, under
+    both schedules and in literal vs linear mode; linear alpha counts the samples; modes agree to the documented tolerance."""
     W, H, N = 1162, 1008, 256
     ctx = gpu_ctx_factory()
     _setup(ctx, golden["scene04"], W, H)
@@ -231,6 +239,13 @@ def test_full_size_many_frames_properties(gpu_ctx_factory, golden):
     assert np.array_equal(_bits(ctx.linear_sum()), _bits(one))
     assert ctx.counters() == c1 and c1["paths"] == W * H * N
     assert np.all(one[..., 3] == N) and np.isfinite(one).all() and np.all(one[..., :3] >= 0)
+    # the wavefront schedule (here split by the library into several launches) gives the same sums
+    ctx.reset_accumulation(); ctx.reset_counters()
+    ctx.set_trace_schedule(ptamd.PT_SCHEDULE_WAVEFRONT)
+    ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LINEAR)
+    assert np.array_equal(_bits(ctx.linear_sum()), _bits(one))
+    assert ctx.counters() == c1
+    ctx.set_trace_schedule(ptamd.PT_SCHEDULE_PERSISTENT)
     ctx.resolve()
     lin = ctx.output()
     ctx.reset_accumulation()
