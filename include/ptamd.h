@@ -68,10 +68,9 @@ int pt_set_constants(pt_context *ctx, const pt_CB_Radix *cb);
  * Equal Morton codes keep ascending primitive index (stable sort). */
 #define PT_BUILD_DEFAULT        0u
 #define PT_BUILD_MORTON_FULL    1u   /* NON-PARITY: quantise to 2^21 cells per axis instead of the reference's 22 */
-#define PT_BUILD_NO_TREE_EXPORT 2u   /* skip writing the reference-layout TreeNode[2n] array (kept: the traversal layout) */
-#define PT_BUILD_KARRAS_LINKS   4u   /* also run the search-based link kernel (the direct counterpart of
-                                        radix_build_cs.hlsl); by default the links come from the closed form of
-                                        the index-keyed tree inside the refit kernels -- same values */
+#define PT_BUILD_KARRAS_LINKS   4u   /* pt_download_tree also runs the search-based link kernel (the direct
+                                        counterpart of radix_build_cs.hlsl) over the links it has written from
+                                        the closed form of the index-keyed tree -- same values */
 int pt_build(pt_context *ctx, unsigned flags);
 
 typedef enum pt_build_stage {
@@ -92,6 +91,9 @@ int pt_download_scene_bound(pt_context *ctx, pt_Bound *bb);             /* RayTr
 int pt_download_morton(pt_context *ctx, uint64_t *codes /* n, primitive order */);
 int pt_download_permutation(pt_context *ctx, int32_t *perm /* n, sorted position -> primitive */);
 int pt_download_sorted_primitives(pt_context *ctx, pt_PrimitiveRayCS *out /* n: ray_cs_primitives */);
+/* tree_uav in the reference's layout.  The build keeps the tree as traversal records (both child
+ * boxes per internal node); the 2n TreeNode records are derived from them on the first call after
+ * a build (links from the closed form, boxes = unions of the child boxes: the refit's own values). */
 int pt_download_tree(pt_context *ctx, pt_TreeNode *out /* 2n: tree_uav */);
 
 /* ---- images -----------------------------------------------------------------

@@ -202,9 +202,8 @@ static int ensure_build_buffers(pt_context *ctx)
     if (!rc) rc = dev_alloc(ctx, &ctx->d_vals[1], (size_t)n);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_morton, (size_t)n);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_block_hist, 256 * nblocks);
-    if (!rc) rc = dev_alloc(ctx, &ctx->d_tree, 2 * (size_t)n + 1);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_wide, (size_t)n);
-    if (!rc) rc = dev_alloc(ctx, &ctx->d_chunk, nchunks);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_chunk, nchunks + (nchunks + 2047) / 2048 + 1);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_tri, (size_t)n);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_shade, (size_t)n);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_tri_sorted, (size_t)n + 1);
@@ -217,10 +216,11 @@ int pt_build(pt_context *ctx, unsigned flags)
 {
     if (!ctx) return PT_ERR_INVALID;
     if (!ctx->d_prims || ctx->n < 1) PT_FAIL(ctx, PT_ERR_INVALID, "pt_build: no primitives uploaded");
-    if (flags & ~(PT_BUILD_MORTON_FULL | PT_BUILD_NO_TREE_EXPORT | PT_BUILD_KARRAS_LINKS)) PT_FAIL(ctx, PT_ERR_INVALID, "pt_build: unknown flag");
+    if (flags & ~(PT_BUILD_MORTON_FULL | PT_BUILD_KARRAS_LINKS)) PT_FAIL(ctx, PT_ERR_INVALID, "pt_build: unknown flag");
     if (int rc = set_device(ctx)) return rc;
     if (int rc = ensure_build_buffers(ctx)) return rc;
     ctx->built = false;
+    ctx->tree_exported = false;
     if (int rc = ptk_build(ctx, flags)) return rc;
     if (int rc = ptk_root_box(ctx)) return rc;
     if (int rc = ptk_sort_tris(ctx)) return rc;
@@ -274,7 +274,12 @@ int pt_download_morton(pt_context *ctx, uint64_t *codes)
 {
     PT_NEED_BUILT(ctx, "pt_download_morton");
     if (!codes) return PT_ERR_INVALID;
-    return d2h(ctx, codes, ctx->d_morton, (size_t)ctx->n * sizeof(uint64_t));
+    if (ctx->morton_bits == 64) return d2h(ctx, codes, ctx->d_morton, (size_t)ctx->n * sizeof(uint64_t));
+    // 32-bit codes on the device: copy into the upper half of the caller's buffer, widen in place
+    uint32_t *narrow = reinterpret_cast<uint32_t *>(codes) + ctx->n;
+    if (int rc = d2h(ctx, narrow, ctx->d_morton, (size_t)ctx->n * sizeof(uint32_t))) return rc;
+    for (int i = 0; i < ctx->n; i++) codes[i] = narrow[i];
+    return PT_OK;
 }
 
 int pt_download_permutation(pt_context *ctx, int32_t *perm)
@@ -300,7 +305,12 @@ int pt_download_tree(pt_context *ctx, pt_TreeNode *out)
 {
     PT_NEED_BUILT(ctx, "pt_download_tree");
     if (!out) return PT_ERR_INVALID;
-    if (ctx->build_flags & PT_BUILD_NO_TREE_EXPORT) PT_FAIL(ctx, PT_ERR_INVALID, "pt_download_tree: built with PT_BUILD_NO_TREE_EXPORT");
+    if (int rc = set_device(ctx)) return rc;
+    if (!ctx->tree_exported) {
+        if (!ctx->d_tree) { if (int rc = dev_alloc(ctx, &ctx->d_tree, 2 * (size_t)ctx->capacity + 1)) return rc; }
+        if (int rc = ptk_export_tree(ctx)) return rc;
+        ctx->tree_exported = true;
+    }
     return d2h(ctx, out, ctx->d_tree, 2 * (size_t)ctx->n * sizeof(pt_TreeNode));
 }
 

@@ -47,7 +47,8 @@ __device__ __forceinline__ float wave_max(float v)
 constexpr int PRIM_DW = 20;   // dwords per PrimitiveRender
 
 __global__ __launch_bounds__(256) void k_bounds(const uint4 *__restrict__ prims16, int n,
-                                                BoxRec *__restrict__ boxes, float *__restrict__ partial)
+                                                BoxRec *__restrict__ boxes, float *__restrict__ partial,
+                                                TriIsect *__restrict__ tri, TriShade *__restrict__ shade)
 {
     __shared__ uint4 stage[256 * PRIM_DW / 4];      // 20480 B
     __shared__ float red[6][4];
@@ -76,6 +77,17 @@ __global__ __launch_bounds__(256) void k_bounds(const uint4 *__restrict__ prims1
         float4 *dst = reinterpret_cast<float4 *>(&boxes[first + t]);
         dst[0] = make_float4(b.mn[0], b.mn[1], b.mn[2], 0.0f);
         dst[1] = make_float4(b.mx[0], b.mx[1], b.mx[2], __int_as_float(b.index));
+        // the triangle records of the trace kernels (vertex + two edges; the three normals), while
+        // the primitive is at hand: a pass of its own would read the 80-byte records again
+        const int matid = reinterpret_cast<const int *>(p)[18];
+        float4 *ti = reinterpret_cast<float4 *>(&tri[first + t]);
+        ti[0] = make_float4(p[0], p[1], p[2], __int_as_float(matid));
+        ti[1] = make_float4(p[6] - p[0], p[7] - p[1], p[8] - p[2], 0.0f);
+        ti[2] = make_float4(p[12] - p[0], p[13] - p[1], p[14] - p[2], 0.0f);
+        float4 *ts = reinterpret_cast<float4 *>(&shade[first + t]);
+        ts[0] = make_float4(p[3], p[4], p[5], __int_as_float(matid));
+        ts[1] = make_float4(p[9], p[10], p[11], 0.0f);
+        ts[2] = make_float4(p[15], p[16], p[17], 0.0f);
     } else {
         const float inf = __uint_as_float(0x7f800000u);
 #pragma unroll
@@ -133,9 +145,10 @@ __device__ __forceinline__ uint64_t spread3(uint64_t v)
     return v;
 }
 
+template <typename K>
 __global__ __launch_bounds__(256) void k_morton(const BoxRec *__restrict__ boxes, int n,
                                                 const unsigned *__restrict__ bbox_enc, float cells,
-                                                uint64_t *__restrict__ codes)
+                                                K *__restrict__ codes)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -149,17 +162,19 @@ __global__ __launch_bounds__(256) void k_morton(const BoxRec *__restrict__ boxes
     uint64_t a = (uint64_t)(((midx - min_x) / (max_x - min_x)) * cells);
     uint64_t b = (uint64_t)(((midy - min_y) / (max_y - min_y)) * cells);
     uint64_t c = (uint64_t)(((midz - min_z) / (max_z - min_z)) * cells);
-    codes[i] = (spread3(a) << 2) | (spread3(b) << 1) | spread3(c);
+    codes[i] = (K)((spread3(a) << 2) | (spread3(b) << 1) | spread3(c));
 }
 
 // ---------------------------------------------------------------------------
-// stage 3: stable LSD radix sort, 8-bit digits, (64-bit key, 32-bit index)
+// stage 3: stable LSD radix sort, 8-bit digits, (32- or 64-bit key, 32-bit index);
+// the last pass leaves only the permutation (nothing reads the sorted keys)
 //   per pass: k_sort_hist (per-workgroup digit counts, LDS histogram)
 //             k_sort_scan (one workgroup per digit scans its row of counts)
 //             k_sort_scatter (wave64 ballot match -> stable ranks, LDS-staged
 //                             reorder, coalesced runs out)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(PT_SORT_THREADS) void k_sort_hist(const uint64_t *__restrict__ keys, int n, int shift,
+template <typename K>
+__global__ __launch_bounds__(PT_SORT_THREADS) void k_sort_hist(const K *__restrict__ keys, int n, int shift,
                                                                uint32_t *__restrict__ block_hist, int nblocks)
 {
     __shared__ uint32_t h[256];
@@ -214,14 +229,14 @@ __global__ __launch_bounds__(256) void k_sort_scan(uint32_t *__restrict__ block_
     if (t == 0) digit_total[d] = carry;
 }
 
-template <bool IOTA>
+template <typename K, bool IOTA, bool KEYS_OUT>
 __global__ __launch_bounds__(PT_SORT_THREADS) void k_sort_scatter(
-    const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-    uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int n, int shift,
+    const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+    K *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int n, int shift,
     const uint32_t *__restrict__ block_off, const uint32_t *__restrict__ digit_total, int nblocks)
 {
     __shared__ uint32_t digit_gbase[256];               // first output slot of each digit
-    __shared__ uint64_t skeys[PT_SORT_TILE];            // 32 KB
+    __shared__ K skeys[PT_SORT_TILE];                   // 16 or 32 KB
     __shared__ uint32_t svals[PT_SORT_TILE];            // 16 KB
     __shared__ uint32_t wave_hist[4][256];              //  4 KB
     __shared__ uint32_t digit_base[256];
@@ -234,14 +249,14 @@ __global__ __launch_bounds__(PT_SORT_THREADS) void k_sort_scatter(
     const long long wave_base = tile_base + (long long)wave * (PT_SORT_ITEMS * 64);
     const int tile_cnt = (int)min((long long)PT_SORT_TILE, (long long)n - tile_base);
 
-    uint64_t key[PT_SORT_ITEMS];
+    K key[PT_SORT_ITEMS];
     uint32_t val[PT_SORT_ITEMS];
     uint32_t rank[PT_SORT_ITEMS];
 #pragma unroll
     for (int r = 0; r < PT_SORT_ITEMS; r++) {
         long long g = wave_base + r * 64 + lane;
         bool valid = g < n;
-        key[r] = valid ? keys_in[g] : ~0ull;
+        key[r] = valid ? keys_in[g] : (K)~(K)0;
         val[r] = IOTA ? (uint32_t)g : (valid ? vals_in[g] : 0u);
     }
     volatile uint32_t *wh = wave_hist[wave];
@@ -283,10 +298,10 @@ __global__ __launch_bounds__(PT_SORT_THREADS) void k_sort_scatter(
     }
     __syncthreads();
     for (int i = t; i < tile_cnt; i += PT_SORT_THREADS) {
-        uint64_t k = skeys[i];
+        K k = skeys[i];
         uint32_t d = (uint32_t)(k >> shift) & 255u;
         uint32_t dst = digit_gbase[d] + block_off[(size_t)d * nblocks + blockIdx.x] + ((uint32_t)i - digit_base[d]);
-        keys_out[dst] = k;
+        if (KEYS_OUT) keys_out[dst] = k;
         vals_out[dst] = svals[i];
     }
 }
@@ -380,15 +395,15 @@ __device__ __forceinline__ void write_tree_node(pt_TreeNode *__restrict__ node, 
     dst[2] = make_float4(U[3], U[4], U[5], 0.0f);
 }
 
-__global__ __launch_bounds__(256) void k_refit_low(const uint32_t *__restrict__ perm, const BoxRec *__restrict__ boxes,
-                                                   int n, int top, pt_TreeNode *__restrict__ tree, WideNode *__restrict__ wide,
-                                                   ChunkBox *__restrict__ chunk)
+__global__ __launch_bounds__(PT_REFIT_CHUNK) void k_refit_low(const uint32_t *__restrict__ perm, const BoxRec *__restrict__ boxes,
+                                                   int n, WideNode *__restrict__ wide, ChunkBox *__restrict__ chunk)
 {
     __shared__ float sb[6][PT_REFIT_CHUNK];          // 24 KB: min.xyz, max.xyz per key slot
     __shared__ int sprim[PT_REFIT_CHUNK];            //  4 KB
     const int t = threadIdx.x;
     const long long base = (long long)blockIdx.x * PT_REFIT_CHUNK;
-    for (int j = t; j < PT_REFIT_CHUNK; j += 256) {
+    {   // one key per lane: every gather of the chunk is in flight at once
+        const int j = t;
         long long key = base + j;
         float b[6] = {0, 0, 0, 0, 0, 0};
         int p = 0;
@@ -397,7 +412,6 @@ __global__ __launch_bounds__(256) void k_refit_low(const uint32_t *__restrict__ 
             const float4 *src = reinterpret_cast<const float4 *>(&boxes[p]);
             float4 lo = src[0], hi = src[1];
             b[0] = lo.x; b[1] = lo.y; b[2] = lo.z; b[3] = hi.x; b[4] = hi.y; b[5] = hi.z;
-            if (tree) write_tree_node(&tree[(long long)n + key], 0, 0, node_id(key >> 1, 1, n), p, b);
         }
 #pragma unroll
         for (int c = 0; c < 6; c++) sb[c][j] = b[c];
@@ -406,7 +420,7 @@ __global__ __launch_bounds__(256) void k_refit_low(const uint32_t *__restrict__ 
     __syncthreads();
     for (int k = 1; k <= PT_REFIT_CHUNK_LOG2; k++) {
         const int nb = PT_REFIT_CHUNK >> k, half = 1 << (k - 1);
-        for (int bl = t; bl < nb; bl += 256) {
+        for (int bl = t; bl < nb; bl += PT_REFIT_CHUNK) {
             const int ls = bl << k;
             const long long s = base + ls;
             if (s + half <= n) {
@@ -423,9 +437,6 @@ __global__ __launch_bounds__(256) void k_refit_low(const uint32_t *__restrict__ 
                 const int left = (k == 1) ? ~sprim[ls] : (int)gamma;
                 const int right = (gamma + 1 == e) ? ~sprim[rs] : (int)(gamma + 1);
                 write_wide(&wide[id], L, R, left, right);
-                if (tree)
-                    write_tree_node(&tree[id], (k == 1) ? n + (int)s : (int)gamma,
-                                    (gamma + 1 == e) ? n + (int)gamma + 1 : (int)(gamma + 1), parent_id(b, k, n, top), 0, U);
 #pragma unroll
                 for (int c = 0; c < 6; c++) sb[c][ls] = U[c];
             }
@@ -435,60 +446,95 @@ __global__ __launch_bounds__(256) void k_refit_low(const uint32_t *__restrict__ 
     if (t < 6) (&chunk[blockIdx.x].mn[0])[t] = sb[t][0];
 }
 
-__global__ __launch_bounds__(256) void k_refit_level(int k, int n, int top, long long nblocks_level,
-                                                     pt_TreeNode *__restrict__ tree, WideNode *__restrict__ wide,
-                                                     ChunkBox *__restrict__ chunk)
+// Levels above a unit (a unit = the box of 2^base consecutive keys: a 1024-key chunk, or a
+// group of units of the previous launch): a workgroup reduces up to 11 levels over 2048
+// consecutive units in LDS and leaves the box of its whole range in `out`.
+constexpr int PT_REFIT_GROUP_LOG2 = 11;
+constexpr int PT_REFIT_GROUP = 1 << PT_REFIT_GROUP_LOG2;
+
+__global__ __launch_bounds__(1024) void k_refit_upper(int base, int top, int n, const ChunkBox *__restrict__ in,
+                                                      long long n_units, WideNode *__restrict__ wide,
+                                                      ChunkBox *__restrict__ out)
 {
+    __shared__ float sb[6][PT_REFIT_GROUP];          // 48 KB
+    const int t = threadIdx.x;
+    const long long unit0 = (long long)blockIdx.x * PT_REFIT_GROUP;
+    for (int j = t; j < PT_REFIT_GROUP; j += 1024) {
+        const long long u = unit0 + j;
+        float b[6] = {0, 0, 0, 0, 0, 0};
+        if (u < n_units) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) { b[c] = in[u].mn[c]; b[3 + c] = in[u].mx[c]; }
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) sb[c][j] = b[c];
+    }
+    __syncthreads();
+    const int last = min(base + PT_REFIT_GROUP_LOG2, top);
+    for (int k = base + 1; k <= last; k++) {
+        const int sh = k - base;                         // units per block of level k: 2^sh
+        const int nb = PT_REFIT_GROUP >> sh;
+        for (int bl = t; bl < nb; bl += 1024) {
+            const int ls = bl << sh;
+            const long long s = (unit0 + ls) << base, half = 1ll << (k - 1);
+            if (s + half <= n) {
+                const int rs = ls + (1 << (sh - 1));
+                float L[6], R[6], U[6];
+#pragma unroll
+                for (int c = 0; c < 6; c++) { L[c] = sb[c][ls]; R[c] = sb[c][rs]; }
+#pragma unroll
+                for (int c = 0; c < 3; c++) { U[c] = fminf(L[c], R[c]); U[3 + c] = fmaxf(L[3 + c], R[3 + c]); }
+                const long long gamma = s + half - 1;
+                const long long e = min(s + (1ll << k) - 1, (long long)n);
+                // above chunk level a single-key right range can only be key n itself
+                const int right = (gamma + 1 == e) ? ~0 : (int)(gamma + 1);
+                write_wide(&wide[node_id(s >> k, k, n)], L, R, (int)gamma, right);
+#pragma unroll
+                for (int c = 0; c < 6; c++) sb[c][ls] = U[c];
+            }
+        }
+        __syncthreads();
+    }
+    if (out && t < 6) (&out[blockIdx.x].mn[0])[t] = sb[t][0];
+}
+
+// ---------------------------------------------------------------------------
+// The tree in the reference's layout (TreeNode[2n]: tree_uav of ray_tracer.cpp:263-279), made
+// on request from the traversal records: leaves n..2n-1 hold the sorted primitives' boxes and
+// indices, internal node boxes are the unions of their children's boxes (the same min / max
+// the refit evaluates), links and parents come from the closed form.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_export_leaves(const uint32_t *__restrict__ perm, const BoxRec *__restrict__ boxes,
+                                                       int n, pt_TreeNode *__restrict__ tree)
+{
+    const int key = blockIdx.x * 256 + threadIdx.x;
+    if (key >= n) return;
+    const int p = (int)perm[key];
+    const float4 *src = reinterpret_cast<const float4 *>(&boxes[p]);
+    const float4 lo = src[0], hi = src[1];
+    const float b[6] = {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z};
+    write_tree_node(&tree[(long long)n + key], 0, 0, node_id(key >> 1, 1, n), p, b);
+}
+
+// blockIdx.y + 1 = level k; one thread per block b of that level
+__global__ __launch_bounds__(256) void k_export_nodes(int n, int top, const WideNode *__restrict__ wide,
+                                                      pt_TreeNode *__restrict__ tree)
+{
+    const int k = (int)blockIdx.y + 1;
     const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (b >= nblocks_level) return;
     const long long s = b << k, half = 1ll << (k - 1);
     if (s + half > n) return;
     const long long gamma = s + half - 1;
     const long long e = min(s + (1ll << k) - 1, (long long)n);
-    ChunkBox *cl = &chunk[s >> PT_REFIT_CHUNK_LOG2];
-    const ChunkBox *cr = &chunk[(gamma + 1) >> PT_REFIT_CHUNK_LOG2];
-    float L[6], R[6], U[6];
-#pragma unroll
-    for (int c = 0; c < 3; c++) { L[c] = cl->mn[c]; L[3 + c] = cl->mx[c]; R[c] = cr->mn[c]; R[3 + c] = cr->mx[c]; }
+    const int id = node_id(b, k, n);
+    const float4 *w = reinterpret_cast<const float4 *>(&wide[id]);
+    const float4 w0 = w[0], w1 = w[1], w2 = w[2];
+    const float L[6] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y}, R[6] = {w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+    float U[6];
 #pragma unroll
     for (int c = 0; c < 3; c++) { U[c] = fminf(L[c], R[c]); U[3 + c] = fmaxf(L[3 + c], R[3 + c]); }
-    const int id = node_id(b, k, n);
-    // above chunk level a single-key right range can only be key n itself
-    const int right = (gamma + 1 == e) ? ~0 : (int)(gamma + 1);
-    write_wide(&wide[id], L, R, (int)gamma, right);
-    if (tree) write_tree_node(&tree[id], (int)gamma, (gamma + 1 == e) ? n + (int)gamma + 1 : (int)(gamma + 1), parent_id(b, k, n, top), 0, U);
-#pragma unroll
-    for (int c = 0; c < 3; c++) { cl->mn[c] = U[c]; cl->mx[c] = U[3 + c]; }
-}
-
-// ---------------------------------------------------------------------------
-// triangle records for traversal / shading
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pack_tris(const uint4 *__restrict__ prims16, int n,
-                                                   TriIsect *__restrict__ tri, TriShade *__restrict__ shade)
-{
-    __shared__ uint4 stage[256 * PRIM_DW / 4];
-    const int t = threadIdx.x;
-    const long long first = (long long)blockIdx.x * 256;
-    const int cnt = (int)min((long long)256, (long long)n - first);
-    const int n16 = cnt * (PRIM_DW / 4);
-    const uint4 *src = prims16 + first * (PRIM_DW / 4);
-    for (int i = t; i < n16; i += 256) stage[i] = src[i];
-    __syncthreads();
-    if (t >= cnt) return;
-    const float *p = reinterpret_cast<const float *>(stage) + t * PRIM_DW;
-    const int matid = reinterpret_cast<const int *>(p)[18];
-    float a[3], e1[3], e2[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { a[k] = p[k]; e1[k] = p[6 + k] - p[k]; e2[k] = p[12 + k] - p[k]; }
-    float4 *ti = reinterpret_cast<float4 *>(&tri[first + t]);
-    ti[0] = make_float4(a[0], a[1], a[2], __int_as_float(matid));
-    ti[1] = make_float4(e1[0], e1[1], e1[2], 0.0f);
-    ti[2] = make_float4(e2[0], e2[1], e2[2], 0.0f);
-    float4 *ts = reinterpret_cast<float4 *>(&shade[first + t]);
-    ts[0] = make_float4(p[3], p[4], p[5], __int_as_float(matid));
-    ts[1] = make_float4(p[9], p[10], p[11], 0.0f);
-    ts[2] = make_float4(p[15], p[16], p[17], 0.0f);
+    write_tree_node(&tree[id], (k == 1) ? n + (int)s : (int)gamma,
+                    (gamma + 1 == e) ? n + (int)gamma + 1 : (int)(gamma + 1), parent_id(b, k, n, top), 0, U);
 }
 
 // sorted {box, index} records in the reference's ray_cs_primitives layout
@@ -507,7 +553,7 @@ __global__ __launch_bounds__(256) void k_export_sorted(const uint32_t *__restric
 // launches), clears them, and makes the pixel's sort key for the trace kernel's work queue: most
 // expensive first.
 __global__ __launch_bounds__(256) void k_cost_keys(uint32_t *__restrict__ cost, uint32_t *__restrict__ pixel_work,
-                                                   int npix, int shift, uint64_t *__restrict__ keys)
+                                                   int npix, int shift, uint32_t *__restrict__ keys)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= npix) return;
@@ -523,6 +569,35 @@ inline int bit_length(unsigned v) { return v ? 32 - __builtin_clz(v) : 0; }
 
 }  // namespace
 
+// `passes` stable 8-bit passes over `keys` (n keys; values start as 0..n-1).  The passes
+// ping-pong between kbuf/vbuf [0] and [1]; returns the index of the vbuf that holds the
+// permutation.  The sorted keys themselves are not produced by the last pass.
+template <typename K>
+static int radix_sort_passes(hipStream_t st, const K *keys, int n, int passes, K *const kbuf[2], uint32_t *const vbuf[2],
+                             uint32_t *block_hist, uint32_t *digit_total)
+{
+    const int nblocks = (n + PT_SORT_TILE - 1) / PT_SORT_TILE;
+    const K *kin = keys;
+    const uint32_t *vin = nullptr;
+    int out = 0;
+    for (int p = 0; p < passes; p++) {
+        const int shift = 8 * p;
+        uint32_t *dtot = digit_total + 256 * p;
+        const bool first = (p == 0), last = (p == passes - 1);
+        hipLaunchKernelGGL(k_sort_hist<K>, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, n, shift, block_hist, nblocks);
+        hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, st, block_hist, dtot, nblocks);
+#define PT_SCATTER(I, KO) hipLaunchKernelGGL((k_sort_scatter<K, I, KO>), dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, vin, \
+                                             kbuf[out], vbuf[out], n, shift, block_hist, dtot, nblocks)
+        if (first) { if (last) PT_SCATTER(true, false); else PT_SCATTER(true, true); }
+        else       { if (last) PT_SCATTER(false, false); else PT_SCATTER(false, true); }
+#undef PT_SCATTER
+        kin = kbuf[out];
+        vin = vbuf[out];
+        out ^= 1;
+    }
+    return out ^ 1;
+}
+
 // Orders the pixels by the work they took in earlier launches (descending, 16-bit keys, two
 // stable radix passes) so that the persistent trace kernel hands out the expensive pixels
 // first and its last wave finishes on cheap ones.  Any order gives the same image.
@@ -530,17 +605,11 @@ int ptk_order_pixels(pt_context *ctx, int shift)
 {
     const int npix = ctx->W * ctx->H;
     hipStream_t st = ctx->stream;
-    const int nblocks = (npix + PT_SORT_TILE - 1) / PT_SORT_TILE;
+    // keys live in d_okeys[0]; pass 0 writes [1], pass 1 writes [0]: the order ends in d_ovals[0]
     hipLaunchKernelGGL(k_cost_keys, dim3((npix + 255) / 256), dim3(256), 0, st, ctx->d_cost, ctx->d_pixel_work, npix, shift, ctx->d_okeys[0]);
-    // pass 0: keys[0] -> keys[1] / vals[1] (identity values); pass 1: -> keys[0] / vals[0]
-    hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, ctx->d_okeys[0], npix, 0, ctx->d_ohist, nblocks);
-    hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, st, ctx->d_ohist, ctx->d_ototal, nblocks);
-    hipLaunchKernelGGL(k_sort_scatter<true>, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, ctx->d_okeys[0], (const uint32_t *)nullptr,
-                       ctx->d_okeys[1], ctx->d_ovals[1], npix, 0, ctx->d_ohist, ctx->d_ototal, nblocks);
-    hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, ctx->d_okeys[1], npix, 8, ctx->d_ohist, nblocks);
-    hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, st, ctx->d_ohist, ctx->d_ototal + 256, nblocks);
-    hipLaunchKernelGGL(k_sort_scatter<false>, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, ctx->d_okeys[1], ctx->d_ovals[1],
-                       ctx->d_okeys[0], ctx->d_ovals[0], npix, 8, ctx->d_ohist, ctx->d_ototal + 256, nblocks);
+    uint32_t *const kb[2] = {ctx->d_okeys[1], ctx->d_okeys[0]};
+    uint32_t *const vb[2] = {ctx->d_ovals[1], ctx->d_ovals[0]};
+    (void)radix_sort_passes<uint32_t>(st, ctx->d_okeys[0], npix, 2, kb, vb, ctx->d_ohist, ctx->d_ototal);
     PT_HIP(ctx, hipGetLastError());
     ctx->order_valid = true;
     return PT_OK;
@@ -553,70 +622,80 @@ int ptk_build(pt_context *ctx, unsigned flags)
 {
     const int n = ctx->n;
     hipStream_t st = ctx->stream;
-    const bool want_tree = !(flags & PT_BUILD_NO_TREE_EXPORT);
     const int grid_n = (n + 255) / 256;
     const uint4 *prims16 = reinterpret_cast<const uint4 *>(ctx->d_prims);
 
-    // scene-box accumulators: +inf encodings for the minima, -inf for the maxima
-    if (want_tree) PT_HIP(ctx, hipMemsetAsync(&ctx->d_tree[2 * (size_t)n], 0, sizeof(pt_TreeNode), st));
-
     PT_HIP(ctx, hipEventRecord(ctx->ev[0], st));
-    hipLaunchKernelGGL(k_bounds, dim3(grid_n), dim3(256), 0, st, prims16, n, ctx->d_boxes, ctx->d_bbox_partial);
+    hipLaunchKernelGGL(k_bounds, dim3(grid_n), dim3(256), 0, st, prims16, n, ctx->d_boxes, ctx->d_bbox_partial, ctx->d_tri, ctx->d_shade);
     hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(1024), 0, st, ctx->d_bbox_partial, grid_n, ctx->d_bbox_enc);
     PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_BOUNDS + 1], st));
 
     const bool full = (flags & PT_BUILD_MORTON_FULL) != 0;
     const float cells = full ? 2097151.0f : (float)PT_MORTON_CODE_LENGTH_EACH;
-    hipLaunchKernelGGL(k_morton, dim3(grid_n), dim3(256), 0, st, ctx->d_boxes, n, ctx->d_bbox_enc, cells, ctx->d_morton);
+    // the reference's codes have 15 bits: 32-bit keys halve the sort's key traffic
+    if (full) hipLaunchKernelGGL(k_morton<uint64_t>, dim3(grid_n), dim3(256), 0, st, ctx->d_boxes, n, ctx->d_bbox_enc, cells, ctx->d_morton);
+    else      hipLaunchKernelGGL(k_morton<uint32_t>, dim3(grid_n), dim3(256), 0, st, ctx->d_boxes, n, ctx->d_bbox_enc, cells,
+                                 reinterpret_cast<uint32_t *>(ctx->d_morton));
+    ctx->morton_bits = full ? 64 : 32;
     PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_MORTON + 1], st));
 
     // The reference quantises each axis to 0..21 (5 bits), so its codes occupy
     // 15 bits: two 8-bit passes sort them completely.  Full-resolution codes
     // have 63 bits: eight passes.
     const int passes = full ? 8 : 2;
-    const int nblocks = (n + PT_SORT_TILE - 1) / PT_SORT_TILE;
-    const uint64_t *kin = ctx->d_morton;
-    const uint32_t *vin = nullptr;
-    int out = 0;
-    for (int p = 0; p < passes; p++) {
-        const int shift = 8 * p;
-        uint32_t *dtot = ctx->d_digit_total + 256 * p;
-        hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, n, shift, ctx->d_block_hist, nblocks);
-        hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, st, ctx->d_block_hist, dtot, nblocks);
-        if (p == 0)
-            hipLaunchKernelGGL(k_sort_scatter<true>, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, vin,
-                               ctx->d_keys[out], ctx->d_vals[out], n, shift, ctx->d_block_hist, dtot, nblocks);
-        else
-            hipLaunchKernelGGL(k_sort_scatter<false>, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, vin,
-                               ctx->d_keys[out], ctx->d_vals[out], n, shift, ctx->d_block_hist, dtot, nblocks);
-        kin = ctx->d_keys[out];
-        vin = ctx->d_vals[out];
-        ctx->sorted_buf = out;
-        out ^= 1;
+    if (full) {
+        uint64_t *const kb[2] = {ctx->d_keys[0], ctx->d_keys[1]};
+        ctx->sorted_buf = radix_sort_passes<uint64_t>(st, ctx->d_morton, n, passes, kb, ctx->d_vals, ctx->d_block_hist, ctx->d_digit_total);
+    } else {
+        uint32_t *const kb[2] = {reinterpret_cast<uint32_t *>(ctx->d_keys[0]), reinterpret_cast<uint32_t *>(ctx->d_keys[1])};
+        ctx->sorted_buf = radix_sort_passes<uint32_t>(st, reinterpret_cast<const uint32_t *>(ctx->d_morton), n, passes, kb, ctx->d_vals,
+                                                      ctx->d_block_hist, ctx->d_digit_total);
     }
     ctx->sort_passes = passes;
     PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_SORT + 1], st));
 
-    // Links (left / right / parent) are written by the refit kernels from the closed form of
-    // the index-keyed tree.  PT_BUILD_KARRAS_LINKS additionally runs the search-based kernel,
-    // which writes the same values (kept as the direct counterpart of radix_build_cs.hlsl).
-    const bool karras = want_tree && (flags & PT_BUILD_KARRAS_LINKS);
+    // The topology of the index-keyed tree is a closed form of n (see the refit kernels): the
+    // refit writes child ids from it, and nothing else has to run for this stage.
     PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_TOPOLOGY + 1], st));
 
     const uint32_t *perm = ctx->d_vals[ctx->sorted_buf];
-    pt_TreeNode *tree = want_tree ? ctx->d_tree : nullptr;
     const int nchunks = (int)(((long long)n + 1 + PT_REFIT_CHUNK - 1) / PT_REFIT_CHUNK);
     const int top = bit_length((unsigned)n);
-    hipLaunchKernelGGL(k_refit_low, dim3(nchunks), dim3(256), 0, st, perm, ctx->d_boxes, n, top, tree, ctx->d_wide, ctx->d_chunk);
-    for (int k = PT_REFIT_CHUNK_LOG2 + 1; k <= top; k++) {
-        long long nb = (((long long)n + 1) + (1ll << k) - 1) >> k;
-        hipLaunchKernelGGL(k_refit_level, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, k, n, top, nb, tree, ctx->d_wide, ctx->d_chunk);
+    hipLaunchKernelGGL(k_refit_low, dim3(nchunks), dim3(PT_REFIT_CHUNK), 0, st, perm, ctx->d_boxes, n, ctx->d_wide, ctx->d_chunk);
+    // levels above the chunks: groups of 2048 units per launch (two launches reach 2^32 keys)
+    {
+        const ChunkBox *in = ctx->d_chunk;
+        ChunkBox *out = ctx->d_chunk + nchunks;          // second half of the buffer, then back
+        long long units = nchunks;
+        for (int base = PT_REFIT_CHUNK_LOG2; base < top; base += PT_REFIT_GROUP_LOG2) {
+            const long long groups = (units + PT_REFIT_GROUP - 1) / PT_REFIT_GROUP;
+            hipLaunchKernelGGL(k_refit_upper, dim3((unsigned)groups), dim3(1024), 0, st, base, top, n, in, units, ctx->d_wide, out);
+            in = out;
+            out = ctx->d_chunk;
+            units = groups;
+        }
     }
-    if (karras) hipLaunchKernelGGL(k_radix_tree, dim3(grid_n), dim3(256), 0, st, n, ctx->d_tree);
     PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_REFIT + 1], st));
 
-    hipLaunchKernelGGL(k_pack_tris, dim3(grid_n), dim3(256), 0, st, prims16, n, ctx->d_tri, ctx->d_shade);
+    // the triangle records were written by the bounds kernel: nothing runs in this stage
     PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_PACK + 1], st));
+    PT_HIP(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+// Fills ctx->d_tree (2n nodes in the reference's layout).  With PT_BUILD_KARRAS_LINKS the links are
+// then rewritten by the search-based kernel that follows radix_build_cs.hlsl: the same values.
+int ptk_export_tree(pt_context *ctx)
+{
+    const int n = ctx->n;
+    hipStream_t st = ctx->stream;
+    const int top = bit_length((unsigned)n);
+    PT_HIP(ctx, hipMemsetAsync(&ctx->d_tree[2 * (size_t)n], 0, sizeof(pt_TreeNode), st));
+    hipLaunchKernelGGL(k_export_leaves, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_vals[ctx->sorted_buf], ctx->d_boxes, n, ctx->d_tree);
+    const long long nb1 = ((long long)n + 2) >> 1;        // blocks of level 1, the widest level
+    hipLaunchKernelGGL(k_export_nodes, dim3((unsigned)((nb1 + 255) / 256), (unsigned)top), dim3(256), 0, st, n, top, ctx->d_wide, ctx->d_tree);
+    if (ctx->build_flags & PT_BUILD_KARRAS_LINKS)
+        hipLaunchKernelGGL(k_radix_tree, dim3((n + 255) / 256), dim3(256), 0, st, n, ctx->d_tree);
     PT_HIP(ctx, hipGetLastError());
     return PT_OK;
 }

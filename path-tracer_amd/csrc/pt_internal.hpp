@@ -86,11 +86,13 @@ struct pt_context {
     float *d_bbox_partial = nullptr;  // 6 floats per bounds workgroup
     uint64_t *d_keys[2] = {nullptr, nullptr};
     uint32_t *d_vals[2] = {nullptr, nullptr};
-    uint64_t *d_morton = nullptr;     // n, primitive order (kept for download)
+    uint64_t *d_morton = nullptr;     // n codes in primitive order (kept for download), 32- or 64-bit
+    int morton_bits = 64;
     int sorted_buf = 0;               // which of d_keys/d_vals holds the sorted result
     uint32_t *d_block_hist = nullptr; // 256 * nblocks
     uint32_t *d_digit_total = nullptr;// 8 * 256
-    pt_TreeNode *d_tree = nullptr;    // 2n+1
+    pt_TreeNode *d_tree = nullptr;    // 2n+1, allocated and filled by the first pt_download_tree after a build
+    bool tree_exported = false;
     WideNode *d_wide = nullptr;       // n
     ChunkBox *d_chunk = nullptr;      // ceil((n+1)/1024)
     float *d_root = nullptr;          // the root's own box (6 floats)
@@ -123,7 +125,7 @@ struct pt_context {
     void *d_wf_hits = nullptr;
     size_t wf_paths = 0;              // paths the three buffers above were sized for
     unsigned *d_wf_counts = nullptr;  // 32 x 64 counters, 128 bytes apart
-    uint64_t *d_okeys[2] = {nullptr, nullptr};
+    uint32_t *d_okeys[2] = {nullptr, nullptr};
     uint32_t *d_ovals[2] = {nullptr, nullptr};   // [0] holds the order when order_valid
     uint32_t *d_ohist = nullptr;      // 256 * ceil(W*H / PT_SORT_TILE)
     uint32_t *d_ototal = nullptr;     // 2 * 256
@@ -150,6 +152,7 @@ int ptk_root_box(pt_context *ctx);
 int ptk_sort_tris(pt_context *ctx);
 int ptk_order_pixels(pt_context *ctx, int shift);
 int ptk_export_sorted(pt_context *ctx, pt_PrimitiveRayCS *d_out);
+int ptk_export_tree(pt_context *ctx);
 int ptk_primary(pt_context *ctx, const pt_camera *cam, const uint8_t *d_albedo);
 int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int mode);
 int ptk_resolve(pt_context *ctx);

@@ -130,17 +130,22 @@ def test_full_resolution_codes_eight_passes(gpu_ctx_factory):
     assert np.array_equal(t["index"][n:], perm)
 
 
-def test_no_tree_export_keeps_traversal_data(gpu_ctx_factory, golden):
+def test_tree_export_is_on_demand_and_repeatable(gpu_ctx_factory, golden):
+    """The reference-layout tree is derived from the traversal records when asked for: asking
+    twice, or after tracing, gives the same bytes; traversal works without ever asking."""
     g = golden["scene01"]
     ctx = gpu_ctx_factory()
     ctx.upload_primitives(g["prims"])
-    ctx.build(ptamd.PT_BUILD_NO_TREE_EXPORT)
-    assert np.array_equal(ctx.permutation(), g["perm"])
-    with pytest.raises(ptamd.PtError):
-        ctx.tree()
-    # traversal still works: a ray down the middle of the box hits something
+    ctx.build()
     hits = ctx.intersect(np.array([[0, 5, 4, 1e-4, 0, 0, -1, 1e4]], dtype=np.float32))
     assert hits["hit"][0] == 1
+    a = ctx.tree()
+    b = ctx.tree()
+    assert a.tobytes() == b.tobytes()
+    for f in ("left", "right", "parent", "index"):
+        assert np.array_equal(a[f], g["tree"][f][:-1]), f
+    assert np.array_equal(a["bound"]["min"], g["tree"]["bound"]["min"][:-1])
+    assert np.array_equal(a["bound"]["max"], g["tree"]["bound"]["max"][:-1])
 
 
 def test_large_soup_properties(gpu_ctx_factory):
