@@ -68,7 +68,7 @@ def bench_build(ctx_factory, n, reps):
         times.append(ctx.build_times())
     ctx.close()
     times = times[1:]
-    tot = sorted(t["total"] - t["pack"] for t in times)[len(times) // 2]     # LBVH proper: bounds .. refit
+    tot = sorted(t["total"] for t in times)[len(times) // 2]     # everything a trace needs: bounds .. refit + triangle records
     med = {k: sorted(t[k] for t in times)[len(times) // 2] for k in ptamd.STAGES}
     gbs = n * BUILD_BYTES_PER_TRI / (tot * 1e-3) / 1e9
     return {
@@ -83,7 +83,7 @@ def bench_build(ctx_factory, n, reps):
 
 
 def build_traffic_from_profile(n):
-    """HBM bytes of one build (bounds .. refit) from the committed PMC summary (FETCH_SIZE doubled as the
+    """HBM bytes of one build from the committed PMC summary (FETCH_SIZE doubled as the
     gfx950 note prescribes, + WRITE_SIZE), valid for the 10M-triangle soup it was collected on."""
     path = os.path.join(ROOT, "profiles", "r01_build_pmc.json")
     if n != 10_000_000 or not os.path.exists(path):
@@ -91,7 +91,7 @@ def build_traffic_from_profile(n):
     try:
         p = json.load(open(path))
         per_build = {"k_bounds": 1, "k_bbox_reduce": 1, "k_morton": 1, "k_sort_hist": 2, "k_sort_scan": 2,
-                     "k_sort_scatter": 2, "k_refit_low": 1, "k_refit_level": 14}
+                     "k_sort_scatter": 2, "k_refit_low": 1, "k_refit_upper": 2}
         return sum(p[k]["hbm_bytes_per_launch"] * c for k, c in per_build.items())
     except Exception:
         return None
@@ -189,16 +189,14 @@ def main():
         step(s)
     ctx.reset_accumulation()
     ctx.reset_counters()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ctx.set_trace_timing(True)      # HIP events around the trace kernel of every launch, on the library's stream
 
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        ev[s][0].record(stream)
         step(s)
-        ev[s][1].record(stream)
     ptdist.reduce_linear_sum(lin, dist if world > 1 else None)
     ctx.resolve()
     torch.cuda.synchronize()
@@ -214,8 +212,9 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dt = float(tmax.item())
     rays, paths = float(tot[1].item()), float(tot[2].item())
-    kern_ms = sorted(a.elapsed_time(b) for a, b in ev)
-    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+    kern_ms = ctx.trace_times()
+    assert len(kern_ms) == args.steps, "one trace kernel launch per step expected"
+    kern_avg_ms = float(kern_ms.mean())
     rays_per_launch = cnt["rays"] / args.steps
     achieved = rays_per_launch * bytes_per_ray / (kern_avg_ms * 1e-3) / 1e9
 

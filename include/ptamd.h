@@ -185,6 +185,15 @@ int pt_set_detailed_counters(pt_context *ctx, int enabled);
 int pt_get_counters(pt_context *ctx, pt_counters *out);   /* synchronises */
 int pt_reset_counters(pt_context *ctx);
 
+/* device-side duration of the trace kernel of every launch since timing was enabled (or since the
+ * last pt_get_trace_times): HIP events on the context's stream around the persistent trace kernel
+ * alone (PT_SCHEDULE_WAVEFRONT: around the first-bounce .. last shading kernel), not around the
+ * accumulate or queue-order kernels.  pt_get_trace_times synchronises, writes at most `capacity`
+ * durations (ms, oldest first), returns how many launches were timed in *count and forgets them.
+ * No counterpart in the reference. */
+int pt_set_trace_timing(pt_context *ctx, int enabled);
+int pt_get_trace_times(pt_context *ctx, float *ms, int capacity, int *count);
+
 /* single closest-hit queries through the traversal kernel, for tests:
  * rays = n_rays x {origin.xyz, t_min, direction.xyz, t_max}; results per ray:
  * hit (0/1), primitive, t, barycentrics (u, v, 1-u-v) */

@@ -115,6 +115,11 @@ void pt_destroy(pt_context *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (auto &e : ctx->trace_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (int k = 0; k < PT_SEED_SLOTS; k++) {
+        if (ctx->h_seeds[k]) (void)hipHostFree(ctx->h_seeds[k]);
+        if (ctx->seed_ev[k]) (void)hipEventDestroy(ctx->seed_ev[k]);
+    }
     free_build(ctx);
     free_images(ctx);
     if (ctx->prims_owned) { void *p = const_cast<pt_PrimitiveRender *>(ctx->d_prims); if (p) (void)hipFree(p); }
@@ -478,13 +483,25 @@ int pt_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, const
     if (ctx->seeds_cap < count) {
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         dev_free(ctx->d_seeds);
+        for (int k = 0; k < PT_SEED_SLOTS; k++) { if (ctx->h_seeds[k]) (void)hipHostFree(ctx->h_seeds[k]); ctx->h_seeds[k] = nullptr; }
         ctx->seeds_cap = 0;
         if (int rc = dev_alloc(ctx, &ctx->d_seeds, (size_t)count)) return rc;
+        for (int k = 0; k < PT_SEED_SLOTS; k++) {
+            PT_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_seeds[k]), (size_t)count * sizeof(uint32_t), hipHostMallocDefault));
+            if (!ctx->seed_ev[k]) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->seed_ev[k], hipEventDisableTiming));
+            ctx->seed_ev_used[k] = false;
+        }
         ctx->seeds_cap = count;
     }
-    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // the previous launch may still read h_seeds' old storage
-    ctx->h_seeds.assign(seeds, seeds + count);
-    PT_HIP(ctx, hipMemcpyAsync(ctx->d_seeds, ctx->h_seeds.data(), (size_t)count * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    // pinned staging slots in rotation: the call does not wait for the previous launch, only for the
+    // copy that last used this slot (PT_SEED_SLOTS calls ago)
+    const int slot = ctx->seed_slot;
+    ctx->seed_slot = (slot + 1) % PT_SEED_SLOTS;
+    if (ctx->seed_ev_used[slot]) PT_HIP(ctx, hipEventSynchronize(ctx->seed_ev[slot]));
+    std::memcpy(ctx->h_seeds[slot], seeds, (size_t)count * sizeof(uint32_t));
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_seeds, ctx->h_seeds[slot], (size_t)count * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    PT_HIP(ctx, hipEventRecord(ctx->seed_ev[slot], ctx->stream));
+    ctx->seed_ev_used[slot] = true;
     if (int rc = ptk_trace_frames(ctx, first_frame, count, mode)) return rc;
     ctx->frame_count = first_frame + count;
     return PT_OK;
@@ -559,6 +576,34 @@ int pt_set_trace_schedule(pt_context *ctx, int schedule)
     if (schedule != PT_SCHEDULE_PERSISTENT && schedule != PT_SCHEDULE_WAVEFRONT)
         PT_FAIL(ctx, PT_ERR_INVALID, "pt_set_trace_schedule: PT_SCHEDULE_PERSISTENT or PT_SCHEDULE_WAVEFRONT");
     ctx->schedule = schedule;
+    return PT_OK;
+}
+
+static void drop_trace_events(pt_context *ctx)
+{
+    for (auto &e : ctx->trace_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    ctx->trace_events.clear();
+}
+
+int pt_set_trace_timing(pt_context *ctx, int enabled)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (int rc = set_device(ctx)) return rc;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drop_trace_events(ctx);
+    ctx->time_trace = enabled != 0;
+    return PT_OK;
+}
+
+int pt_get_trace_times(pt_context *ctx, float *ms, int capacity, int *count)
+{
+    if (!ctx || !count || (capacity > 0 && !ms)) return PT_ERR_INVALID;
+    if (int rc = set_device(ctx)) return rc;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *count = (int)ctx->trace_events.size();
+    for (int i = 0; i < *count && i < capacity; i++)
+        PT_HIP(ctx, hipEventElapsedTime(&ms[i], ctx->trace_events[i].first, ctx->trace_events[i].second));
+    drop_trace_events(ctx);
     return PT_OK;
 }
 

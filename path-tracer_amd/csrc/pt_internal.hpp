@@ -64,6 +64,8 @@ constexpr int PT_SORT_TILE = PT_SORT_THREADS * PT_SORT_ITEMS;   // 4096 keys per
 constexpr int PT_REFIT_CHUNK_LOG2 = 10;
 constexpr int PT_REFIT_CHUNK = 1 << PT_REFIT_CHUNK_LOG2;        // 1024 sorted keys per workgroup
 
+constexpr int PT_SEED_SLOTS = 4;
+
 struct pt_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -132,13 +134,18 @@ struct pt_context {
     bool order_valid = false;
     uint32_t frame_count = 0;
     uint32_t *d_seeds = nullptr;
-    std::vector<uint32_t> h_seeds;    // host staging that outlives the async copy
+    uint32_t *h_seeds[PT_SEED_SLOTS] = {};   // pinned host staging, used in rotation
+    hipEvent_t seed_ev[PT_SEED_SLOTS] = {};  // recorded after the copy out of the slot
+    bool seed_ev_used[PT_SEED_SLOTS] = {};
+    int seed_slot = 0;
     uint32_t seeds_cap = 0;
 
     // options / counters
     int stack_entries = 0;            // 0 = automatic
     int schedule = 0;                 // PT_SCHEDULE_*
     bool detailed = false;
+    bool time_trace = false;          // record an event pair around the trace kernel of each launch
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;
     DevCounters *d_counters = nullptr;
 };
 

@@ -1482,6 +1482,12 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
         const uint32_t cnt = (count - off < per_launch) ? count - off : per_launch;
         const uint32_t first = first_frame + off;
         const uint32_t *seeds = ctx->d_seeds + off;
+        hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+        if (ctx->time_trace) {
+            PT_HIP(ctx, hipEventCreate(&ev_begin));
+            PT_HIP(ctx, hipEventCreate(&ev_end));
+            ctx->trace_events.emplace_back(ev_begin, ev_end);
+        }
         if (wavefront) {
             // per depth and segment: queue length and the extend kernel's read head
             const size_t per_depth = (size_t)WF_SEGS * WF_CSTRIDE;
@@ -1495,6 +1501,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             Tuning wt = {16, 12};
             if (const char *e = getenv("PTAMD_WF_REFILL_T")) wt.refill_t = atoi(e);
             if (const char *e = getenv("PTAMD_WF_LEAF_T")) wt.leaf_t = atoi(e);
+            if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream));
             hipLaunchKernelGGL(k_wf_first, fgrid, dim3(256), 0, ctx->stream, sv, ctx->W, ctx->H, ctx->d_diffuse, ctx->d_normal,
                                ctx->d_world, first, cnt, seeds, ctx->d_samples, queue[0], qcount + per_depth, seg_size, ctx->d_counters);
             PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_extend<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -1510,6 +1517,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
                 hipLaunchKernelGGL(k_wf_shade, sgrid, dim3(256), 0, ctx->stream, sv, qin, hits, qcount + d * per_depth, qout,
                                    qcount + (d + 1) * per_depth, seg_size, ctx->d_samples, first, (unsigned)npix);
             }
+            if (ev_end) PT_HIP(ctx, hipEventRecord(ev_end, ctx->stream));
             PT_HIP(ctx, hipGetLastError());
             if (getenv("PTAMD_PRINT_WF")) {      // diagnostics: queue length per depth
                 std::vector<unsigned> h(32 * per_depth);
@@ -1539,8 +1547,10 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
                 ctx->W, ctx->H, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, seeds, \
                 ctx->d_samples, ctx->d_counters, ctx->d_work, \
                 ctx->order_valid ? ctx->d_ovals[0] : (const uint32_t *)nullptr, ctx->d_pixel_work, (uint32_t)chunk, tune); } while (0)
+            if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream));
             if (ctx->detailed) PT_LAUNCH_LDS(true); else PT_LAUNCH_LDS(false);
 #undef PT_LAUNCH_LDS
+            if (ev_end) PT_HIP(ctx, hipEventRecord(ev_end, ctx->stream));
             PT_HIP(ctx, hipGetLastError());
             // queue order of the next launch from the decaying per-pixel iteration counts (about
             // eight launches of at most 2^12 iterations per frame), reduced to 16 bits
@@ -1555,8 +1565,10 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             const size_t lds = stack_bytes(ctx);
 #define PT_LAUNCH_TRACE(C) hipLaunchKernelGGL((k_trace<C>), grid, block, lds, ctx->stream, sv, ctx->W, ctx->H, \
                 ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, seeds, ctx->d_samples, ctx->d_counters, tune)
+            if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream));
             if (ctx->detailed) PT_LAUNCH_TRACE(true); else PT_LAUNCH_TRACE(false);
 #undef PT_LAUNCH_TRACE
+            if (ev_end) PT_HIP(ctx, hipEventRecord(ev_end, ctx->stream));
             PT_HIP(ctx, hipGetLastError());
         }
         const dim3 agrid((unsigned)((npix + 255) / 256));

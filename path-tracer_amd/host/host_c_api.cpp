@@ -41,6 +41,7 @@ void pth_scene_materials(const Scene *s, float *out)
         out += 12;
     }
 }
+int pth_snapshot_due(int frame_count) { return RayTracer::snapshotDue(frame_count) ? 1 : 0; }
 float pth_parse_real(const char *text) { return objl::parse_real(text, text + std::strlen(text), 0.0); }
 
 // ---- RayTracer (GPU) -----------------------------------------------------------

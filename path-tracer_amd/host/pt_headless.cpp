@@ -1,6 +1,8 @@
 // Headless driver: what the reference's windowed application does in trace mode
 // (reference: CS.cpp:108-117 initScene, :396-514 trace loop and snapshots).
-//   pt_headless scene.obj [width height frames out.bmp]
+//   pt_headless scene.obj [width height frames out.bmp [snapshot_dir]]
+// With snapshot_dir the run also writes the reference's scheduled snapshots
+// ("<W>X<H>frame_<count>.bmp" at 50, 100, 200, 500, 1000, ... frames, CS.cpp:446-479,507-514).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -9,18 +11,22 @@
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) { std::fprintf(stderr, "usage: %s scene.obj [width height frames out.bmp]\n", argv[0]); return 2; }
+    if (argc < 2) { std::fprintf(stderr, "usage: %s scene.obj [width height frames out.bmp [snapshot_dir]]\n", argv[0]); return 2; }
     RayTracer ray_tracer;
     ray_tracer.width = argc > 2 ? std::atoi(argv[2]) : 1162;
     ray_tracer.height = argc > 3 ? std::atoi(argv[3]) : 1008;
     const int frames = argc > 4 ? std::atoi(argv[4]) : 100;
     const char *out = argc > 5 ? argv[5] : "snapshot.bmp";
+    const char *snapshot_dir = argc > 6 ? argv[6] : nullptr;
     ray_tracer.loadScene(argv[1]);
     ray_tracer.loadShaders();
     ray_tracer.createBuffers();
     if (!ray_tracer.ok()) { std::fprintf(stderr, "%s\n", ray_tracer.lastError().c_str()); return 1; }
     const auto t0 = std::chrono::steady_clock::now();
-    while (ray_tracer.frame_count < frames && ray_tracer.ok()) ray_tracer.run();
+    while (ray_tracer.frame_count < frames && ray_tracer.ok()) {
+        ray_tracer.run();
+        if (snapshot_dir) ray_tracer.saveScheduledSnapshot(snapshot_dir);
+    }
     if (!ray_tracer.saveBMP(out)) { std::fprintf(stderr, "%s\n", ray_tracer.lastError().c_str()); return 1; }
     const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("%d triangles, %dx%d, %d frames in %.3f s (%.1f frames/s) -> %s\n", ray_tracer.primitive_count,

@@ -194,6 +194,23 @@ std::vector<TreeNode> RayTracer::readTree()
     return t;
 }
 
+bool RayTracer::snapshotDue(int frame_count)
+{
+    static const int schedule[] = {50, 100, 200, 500, 1000, 1500, 2000, 3000, 5000, 8000, 10000, 12000, 16000, 20000,
+                                   30000, 35000, 40000, 50000, 60000, 70000, 80000, 100000, 120000, 150000, 200000,
+                                   300000, 400000};
+    for (int f : schedule) if (f == frame_count) return true;
+    return false;
+}
+
+bool RayTracer::saveScheduledSnapshot(const char *dir)
+{
+    if (!snapshotDue(frame_count)) return false;
+    char name[512];
+    std::snprintf(name, sizeof(name), "%s/%dX%dframe_%d.bmp", dir && *dir ? dir : ".", width, height, frame_count);
+    return saveBMP(name);
+}
+
 bool RayTracer::saveBMP(const char *path)
 {
     const std::vector<uint8_t> img = readDisplay();

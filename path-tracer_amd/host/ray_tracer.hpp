@@ -74,6 +74,10 @@ public:
     std::vector<uint8_t> readDisplay();                 // RGBA8
     std::vector<TreeNode> readTree();                   // 2 * primitive_count nodes
     bool saveBMP(const char *path);                     // the display image (CS.cpp:507-514)
+    // the frame counts at which the reference saves "<width>X<height>frame_<count>.bmp" (CS.cpp:446-479)
+    static bool snapshotDue(int frame_count);
+    // saveBMP under that name in `dir` when frame_count is on the schedule; returns whether a file was written
+    bool saveScheduledSnapshot(const char *dir);
     const std::string &lastError() const { return error_; }
     bool ok() const { return error_.empty(); }
     pt_context *context() { return ctx_; }

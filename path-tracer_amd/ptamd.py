@@ -43,7 +43,7 @@ EXPORTS = (
     "pt_trace", "pt_trace_frames", "pt_frame_seeds", "pt_get_frame_count", "pt_reset_accumulation",
     "pt_linear_sum_device_ptr", "pt_resolve",
     "pt_download_output", "pt_download_display", "pt_output_device_ptr",
-    "pt_set_stack_size", "pt_set_trace_schedule", "pt_set_detailed_counters", "pt_get_counters", "pt_reset_counters", "pt_intersect",
+    "pt_set_stack_size", "pt_set_trace_schedule", "pt_set_trace_timing", "pt_get_trace_times", "pt_set_detailed_counters", "pt_get_counters", "pt_reset_counters", "pt_intersect",
 )
 
 
@@ -282,6 +282,16 @@ class Context:
 
     def set_trace_schedule(self, schedule):
         self._ck(self.L.pt_set_trace_schedule(self.h, C.c_int(schedule)))
+
+    def set_trace_timing(self, on):
+        self._ck(self.L.pt_set_trace_timing(self.h, C.c_int(1 if on else 0)))
+
+    def trace_times(self, capacity=65536):
+        """Device-side duration (ms) of the trace kernel of every launch since timing was enabled."""
+        ms = np.zeros(capacity, dtype=np.float32)
+        cnt = C.c_int(0)
+        self._ck(self.L.pt_get_trace_times(self.h, _p(ms), C.c_int(capacity), C.byref(cnt)))
+        return ms[:min(cnt.value, capacity)].copy()
 
     def set_detailed_counters(self, on):
         self._ck(self.L.pt_set_detailed_counters(self.h, C.c_int(1 if on else 0)))

@@ -1,17 +1,15 @@
 """Reads the per-pass counter CSVs of scripts/pmc_run.sh and writes a per-kernel summary (JSON + text)."""
-import csv, glob, json, os, sys
+import csv, glob, json, os, re, sys
 from collections import defaultdict
 src, out_json = sys.argv[1], sys.argv[2]
 acc = defaultdict(lambda: defaultdict(float)); calls = defaultdict(lambda: defaultdict(int))
 for f in glob.glob(os.path.join(src, "*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip()
-        if "k_trace_lds" in r["Kernel_Name"]:
-            k = "k_trace_lds" + ("<detailed>" if "k_trace_lds<true" in r["Kernel_Name"] else "")
-        elif "k_trace" in r["Kernel_Name"]:
-            k = "k_trace" + ("<detailed>" if "k_trace<true" in r["Kernel_Name"] else "")
-        if "k_sort_scatter" in r["Kernel_Name"]:
-            k = "k_sort_scatter"
+        name = r["Kernel_Name"]
+        m = re.search(r"(k_\w+)", name)
+        k = m.group(1) if m else name.replace("void ", "").split("(")[0].strip()
+        if k in ("k_trace_lds", "k_trace", "k_wf_extend") and (k + "<true") in name:
+            k += "<detailed>"
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[k][r["Counter_Name"]] += 1
 res = {}
 for k in acc:

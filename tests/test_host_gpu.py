@@ -71,5 +71,13 @@ def test_headless_driver_writes_snapshot(tmp_path):
     data = out.read_bytes()
     assert data[:2] == b"BM" and len(data) == 54 + 160 * 3 * 128
     assert max(data[54:]) > 100                          # the light is visible
+    # scheduled snapshots under the reference's file names (CS.cpp:446-479,507-514)
+    snaps = tmp_path / "snaps"
+    snaps.mkdir()
+    res = subprocess.run([exe, "scene01.obj", "48", "40", "100", str(out), str(snaps)], cwd=os.path.join(GOLDEN, "scenes"),
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    assert sorted(p.name for p in snaps.iterdir()) == ["48X40frame_100.bmp", "48X40frame_50.bmp"]
+    assert (snaps / "48X40frame_100.bmp").read_bytes() == out.read_bytes()
     bad = subprocess.run([exe, "missing.obj"], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 1 and "cannot open" in bad.stderr

@@ -112,3 +112,10 @@ def test_polygon_and_material_rules(host, tmp_path, monkeypatch):
         assert not mats[2].any()                                        # default material: all zero
     finally:
         host.pth_scene_free(s)
+
+
+def test_snapshot_schedule_is_the_reference_list(host):
+    """CS.cpp:446-479: the frame counts at which the reference writes "<W>X<H>frame_<n>.bmp"."""
+    due = [f for f in range(0, 400001) if host.pth_snapshot_due(f)]
+    assert due == [50, 100, 200, 500, 1000, 1500, 2000, 3000, 5000, 8000, 10000, 12000, 16000, 20000, 30000, 35000,
+                   40000, 50000, 60000, 70000, 80000, 100000, 120000, 150000, 200000, 300000, 400000]
