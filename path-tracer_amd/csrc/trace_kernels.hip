@@ -531,6 +531,25 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, in
 }
 
 // ---------------------------------------------------------------------------
+// Path seeds of one launch: seed(pixel, frame) = rand_init(pixel id, g_random[0] of the frame)
+// (ray_tracing.hlsl:410, helpers.hlsli:5-19), written into the w component of the path's sample slot.
+// The 16-round hash costs ~290 instructions; inside the persistent kernel a wave would run it in
+// nearly every refill round for the few lanes that start a path, here every lane does useful work.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_path_seeds(int W, unsigned npix, uint32_t count, const uint32_t *__restrict__ seeds,
+                                                    float4 *__restrict__ samples)
+{
+    const size_t total = (size_t)npix * count;
+    for (size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x; slot < total; slot += (size_t)gridDim.x * 256) {
+        const unsigned fl = (unsigned)(slot / npix), px = (unsigned)(slot - (size_t)fl * npix);
+        const unsigned y = px / (unsigned)W, x = px - y * (unsigned)W;
+        // ray_tracing.hlsl:410: uint(launchIndex.x + launchIndex.y * viewportDims.x), in float
+        const uint32_t pixel_id = (uint32_t)((float)x + (float)y * (float)W);
+        samples[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rand_init(pixel_id, seeds[fl])));
+    }
+}
+
+// ---------------------------------------------------------------------------
 // The same state machine with the tree held in LDS, for scenes whose node
 // records fit (48 bytes per internal node: the two child boxes).
 //
@@ -602,7 +621,6 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
     unsigned px = 0;
     int matid0 = 0;
     pt_f3 hit_pos = pt_mk3(0, 0, 0), multi0 = pt_mk3(0, 0, 0), view0 = pt_mk3(0, 0, 0), normal0 = pt_mk3(0, 0, 0);
-    uint32_t pixel_id = 0;
     uint32_t f = 0, f_end = 0;          // next local frame of the item, one past its last
     uint32_t work = 0;                  // traversal iterations this item has occupied its lane
     // per-path / per-ray state
@@ -654,7 +672,6 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                         f = (item - slot * chunks) * chunk;
                         f_end = min(f + chunk, count);
                         work = 0;
-                        const unsigned y = px / (unsigned)W, x = px - y * (unsigned)W;
                         const uchar4 dif8 = reinterpret_cast<const uchar4 *>(diffuse_tex)[px];
                         const float4 nrm4 = normal_tex[px];
                         const float4 pos4 = world_tex[px];
@@ -668,8 +685,6 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                             if (mats[matid0].ns > 1) multi0 = pt_mk3(1, 1, 1);
                             view0 = pt_normalize3(pt_sub3(hit_pos, g_pos));
                             normal0 = pt_normalize3(pt_mk3(nrm4.x, nrm4.y, nrm4.z));
-                            // ray_tracing.hlsl:410: uint(launchIndex.x + launchIndex.y * viewportDims.x), in float
-                            pixel_id = (uint32_t)((float)x + (float)y * (float)W);
                             path_active = false;
                             cur_k = K_IDLE;
                             has_px = true;
@@ -720,7 +735,8 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                         if (f < f_end) {
                             // new path of frame f (ray_tracing.hlsl:348-370, 410)
                             cnt.paths++;
-                            seed = rand_init(pixel_id, seeds[f]);
+                            // rand_init(pixel, seed of the frame), left in the path's sample slot by k_path_seeds
+                            seed = __float_as_uint(samples[(size_t)f * npix + px].w);
                             multi = multi0;
                             itr = 1;
                             ray.o = hit_pos;
@@ -1541,6 +1557,8 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             chunk = (cnt + (cnt + chunk - 1) / chunk - 1) / ((cnt + chunk - 1) / chunk);
             if (const char *e = getenv("PTAMD_CHUNK")) { chunk = (unsigned long long)atoi(e); if (chunk < 1) chunk = 1; if (chunk > cnt) chunk = cnt; }
             PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
+            hipLaunchKernelGGL(k_path_seeds, dim3((unsigned)ctx->num_cus * 16u), dim3(256), 0, ctx->stream, ctx->W, (unsigned)npix, cnt,
+                               seeds, ctx->d_samples);
 #define PT_LAUNCH_LDS(C) do { \
             PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_lds<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
             hipLaunchKernelGGL((k_trace_lds<C>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
