@@ -3,7 +3,7 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json config 2): scene04 at 1162x1008, progressive accumulation with the
+Workload: scene04 at 1162x1008, progressive accumulation with the
 fixed-seed convention.  One STEP = one block of 32 consecutive frames (one cycle of the shader's
 frame-index stratification) = 32 paths per pixel, traced by ONE launch of the path-trace kernel
 per GPU.  The default K = 32 steps is the 1024 spp of that config.  With N GPUs every rank holds

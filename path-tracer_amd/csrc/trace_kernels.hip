@@ -11,11 +11,17 @@
 // and no fast-math.  Work is VALU / latency bound on L2-resident trees; there
 // is no dense contraction here, so no matrix-core use.
 //
-// Execution shape: one lane per pixel, a wave covers an 8x8 pixel tile.  A lane
-// runs its pixel's frames back to back (a finished path immediately starts the
-// next frame's path), so lanes of a wave stay busy although path lengths
-// differ.  The traversal keeps the current node in a register and only the
-// pending right children (id + entry distance) on a per-lane LDS stack.
+// Execution shape.  Every path writes its radiance sample into a [frame][pixel]
+// staging buffer and k_accumulate folds the frames of a launch into the images
+// in frame order, so which lane traces which path never enters a result.
+//   k_trace      any tree (nodes in global memory): one lane per pixel, a wave
+//                covers an 8x8 tile, a lane runs its pixel's frames back to back.
+//   k_trace_lds  trees that fit in LDS: one persistent workgroup per CU, lanes
+//                take (pixel, frame chunk) items from a global queue, most
+//                expensive pixels first.
+//   k_wf_*       the same paths bounce by bounce over queues (optional schedule).
+// All of them keep the current node in a register and only the pending right
+// children on a per-lane LDS stack.
 #include "pt_internal.hpp"
 
 #include <cstdio>

@@ -24,6 +24,7 @@ bool RayTracer::ensureContext()
 
 void RayTracer::loadScene(const char *filename)
 {
+    flush();
     error_.clear();
     if (!scene.loadObj(filename)) { error_ = "loadObj: " + scene.error; return; }
 
@@ -79,6 +80,7 @@ void RayTracer::createBuffers()
 void RayTracer::updateConstants()
 {
     if (!ctx_) return;
+    flush();      // queued frames belong to the old constants / G-buffer
     CB_Radix cb;
     std::memset(&cb, 0, sizeof(cb));
     cb.node_count = primitive_count;
@@ -101,6 +103,7 @@ void RayTracer::updateConstants()
 void RayTracer::renderGBuffer()
 {
     if (!ctx_) return;
+    flush();      // queued frames belong to the old constants / G-buffer
     uint8_t albedo[PT_MAX_MATERIALS][4];
     std::memset(albedo, 0, sizeof(albedo));
     size_t i = 0;
@@ -131,6 +134,7 @@ void RayTracer::run()
 
 void RayTracer::resize(int w, int h)
 {
+    flush();
     width = w;
     height = h;
     frame_count = 0;
@@ -159,13 +163,27 @@ void RayTracer::trace()
     } else {
         pt_frame_seeds(base_seed, (uint32_t)frame_count, 1, &seed);
     }
-    if (check(pt_trace(ctx_, (uint32_t)frame_count, seed), "pt_trace")) frame_count += 1;
+    // a caller that moved frame_count (the reference's ACC toggle sets it to 0) starts a new batch
+    if (!pending_seeds_.empty() && frame_count != pending_first_ + (int)pending_seeds_.size()) flush();
+    if (pending_seeds_.empty()) pending_first_ = frame_count;
+    pending_seeds_.push_back(seed);
+    frame_count += 1;
+    if ((int)pending_seeds_.size() >= (frames_per_launch < 1 ? 1 : frames_per_launch)) flush();
+}
+
+void RayTracer::flush()
+{
+    if (pending_seeds_.empty() || !ctx_) return;
+    check(pt_trace_frames(ctx_, (uint32_t)pending_first_, (uint32_t)pending_seeds_.size(), pending_seeds_.data(),
+                          PT_ACCUM_LITERAL), "pt_trace_frames");
+    pending_seeds_.clear();
 }
 
 void RayTracer::finish() {}
 
 void RayTracer::release()
 {
+    pending_seeds_.clear();
     if (ctx_) pt_destroy(ctx_);
     ctx_ = nullptr;
     has_built_ = false;
@@ -175,6 +193,7 @@ void RayTracer::release()
 
 std::vector<float> RayTracer::readOutput()
 {
+    flush();
     std::vector<float> img((size_t)width * height * 4);
     if (ctx_) check(pt_download_output(ctx_, img.data()), "pt_download_output");
     return img;
@@ -182,6 +201,7 @@ std::vector<float> RayTracer::readOutput()
 
 std::vector<uint8_t> RayTracer::readDisplay()
 {
+    flush();
     std::vector<uint8_t> img((size_t)width * height * 4);
     if (ctx_) check(pt_download_display(ctx_, img.data()), "pt_download_display");
     return img;

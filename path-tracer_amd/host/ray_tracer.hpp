@@ -64,6 +64,11 @@ public:
     uint32_t base_seed = 1;
     bool use_random_device = false;
     bool srgb_albedo_quirk = true;
+    // run() queues its frame; queued frames are traced by ONE launch when this many are waiting or
+    // when a result is needed (any read, snapshot, resize, new constants).  The images are those of
+    // one launch per frame; a launch of 32 frames takes half the time of 32 launches.  1 = launch in run().
+    int frames_per_launch = 32;
+    void flush();
     float eye[3] = {0.0f, 5.0f, 23.0f};                 // CS.cpp:49
     float at[3] = {0.0f, 5.0f, 0.0f};                   // CS.cpp:50
     // material constants + eye into CB_Radix (reference: CS.cpp:405-439)
@@ -86,6 +91,8 @@ private:
     pt_context *ctx_ = nullptr;
     bool has_built_ = false;
     bool gbuffer_ready_ = false;
+    int pending_first_ = 0;                 // first of the queued frames
+    std::vector<uint32_t> pending_seeds_;   // their seeds; frame pending_first_ + i uses [i]
     std::string error_;
     bool check(int rc, const char *what);
     bool ensureContext();

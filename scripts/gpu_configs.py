@@ -1,4 +1,4 @@
-"""Runs the other BASELINE configurations once: scene02/03 at 3840x2160, and a large soup render
+"""Runs the other named configurations once: the four scenes at 1162x1008 and 3840x2160, and a large soup render
 (global-memory tree, deep stack) -- timings only."""
 import os, sys, time
 import numpy as np

@@ -57,6 +57,15 @@ def test_raytracer_class_matches_oracle(golden, monkeypatch):
             old, outu, _, _ = orc.trace_frame(sc, gb, f, seeds[f], old)
         assert out.tobytes() == old.tobytes()
         assert np.array_equal(disp, outu)
+        # run() queues frames and traces them in batches (here 32 + 8): same images as one launch per frame
+        more = 40
+        assert L.pth_tracer_run(r, more) == frames + more, L.pth_tracer_error(r)
+        assert L.pth_tracer_read(r, out.ctypes.data_as(C.c_void_p), disp.ctypes.data_as(C.c_void_p)) == 0
+        seeds = orc.frame_seeds(1, 0, frames + more)
+        for f in range(frames, frames + more):
+            old, outu, _, _ = orc.trace_frame(sc, gb, f, seeds[f], old)
+        assert out.tobytes() == old.tobytes()
+        assert np.array_equal(disp, outu)
     finally:
         L.pth_tracer_free(r)
 

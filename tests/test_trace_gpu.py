@@ -283,3 +283,17 @@ def test_converged_image_close_to_reference_snapshot(gpu_ctx_factory, golden):
             assert rmse < 18.0
     assert means[True].max() < 1.5
     assert means[False].min() > 3.0
+
+
+def test_trace_timing_reports_one_duration_per_launch(gpu_ctx_factory, golden):
+    ctx = gpu_ctx_factory()
+    _setup(ctx, golden["scene01"], 96, 80)
+    ctx.set_trace_timing(True)
+    for k in range(3):
+        ctx.trace_frames(4 * k, ptamd.frame_seeds(1, 4 * k, 4), ptamd.PT_ACCUM_LINEAR)
+    ms = ctx.trace_times()
+    assert len(ms) == 3 and np.all(ms > 0) and np.all(ms < 1000)
+    assert len(ctx.trace_times()) == 0                   # reported once
+    ctx.set_trace_timing(False)
+    ctx.trace_frames(12, ptamd.frame_seeds(1, 12, 4), ptamd.PT_ACCUM_LINEAR)
+    assert len(ctx.trace_times()) == 0
