@@ -184,6 +184,42 @@ def test_soup_scene_with_all_material_kinds(gpu_ctx_factory):
     assert np.isfinite(old[..., :3]).mean() > 0.99
 
 
+@pytest.mark.parametrize("schedule", SCHEDULES)
+@pytest.mark.parametrize("n,W,H", [(1, 7, 5), (2, 64, 1), (3, 1, 1), (5, 65, 3), (64, 33, 31)])
+def test_tiny_scenes_and_images(gpu_ctx_factory, n, W, H, schedule):
+    """Smallest trees (one triangle: the root's right child is the out-of-range leaf) and images
+    smaller than a wave, narrower than a tile, of one pixel."""
+    rng = np.random.default_rng(n)
+    prims = make_soup(n, seed=n)
+    # large triangles in front of the camera so that most pixels hit something
+    prims["vertices"]["pos"] = (rng.random((n, 3, 3), dtype=np.float32) * np.float32(2) - np.float32(0.5))
+    prims["vertices"]["pos"][..., 2] *= np.float32(0.3)
+    prims["matid"] = np.arange(n) % 4
+    cb = soup_cb(n)
+    ob = orc.build(prims)
+    ctx = gpu_ctx_factory()
+    ctx.set_trace_schedule(schedule)
+    ctx.upload_primitives(prims); ctx.set_constants(cb); ctx.build(); ctx.resize(W, H)
+    kd = [list(cb["mats"][0][m]["kd"][:3]) for m in range(16)]
+    alb = ptamd.albedo_table(kd)
+    ctx.primary_hits(ptamd.default_camera(eye=(0.5, 0.5, 3.0), at=(0.5, 0.5, 0.5)), alb)
+    sc = orc.OracleScene(prims, ob["tree"], cb)
+    gb = orc.primary(sc, orc.default_camera(eye=(0.5, 0.5, 3.0), at=(0.5, 0.5, 0.5)), W, H, alb)
+    d, nn, w = ctx.download_gbuffer()
+    assert np.array_equal(d, gb[0]) and np.array_equal(_bits(nn), _bits(gb[1])) and np.array_equal(_bits(w), _bits(gb[2]))
+    seeds = ptamd.frame_seeds(3, 0, 9)
+    ctx.set_detailed_counters(True)
+    ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LITERAL)
+    old = np.zeros((H, W, 4), np.float32)
+    tot = dict(paths=0, rays=0, node_visits=0, box_tests=0, tri_tests=0)
+    for f in range(9):
+        old, outu, _, c = orc.trace_frame(sc, gb, f, seeds[f], old)
+        tot = {k: tot[k] + c[k] for k in tot}
+    assert np.array_equal(_bits(ctx.output()), _bits(old))
+    assert np.array_equal(ctx.display(), outu)
+    assert ctx.counters() == tot and tot["paths"] == 9 * W * H
+
+
 def test_deep_tree_needs_opt_in(gpu_ctx_factory):
     n = 40000                                               # 16 levels: beyond the reference's stack
     prims = make_soup(n, seed=3)
