@@ -4,9 +4,9 @@
   python bench.py --gpus N --steps K --warmup W
 
 Workload: scene04 at 1162x1008, progressive accumulation with the
-fixed-seed convention.  One STEP = one block of 32 consecutive frames (one cycle of the shader's
-frame-index stratification) = 32 paths per pixel, traced by ONE launch of the path-trace kernel
-per GPU.  The default K = 32 steps is the 1024 spp of that config.  With N GPUs every rank holds
+fixed-seed convention.  One STEP = one block of 128 consecutive frames (four cycles of the shader's
+frame-index stratification) = 128 paths per pixel, traced by ONE launch of the path-trace kernel
+per GPU.  The default K = 8 steps is the 1024 spp of that config.  With N GPUs every rank holds
 the scene and its tree, traces its own blocks (weak scaling), and the float accumulation sums are
 merged by one RCCL all-reduce + resolve at the end, inside the timed region.
 
@@ -125,7 +125,7 @@ def cpu_baseline(g, W, H, budget_s=12.0, max_frames=32):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scene", default="scene04")
     ap.add_argument("--width", type=int, default=1162)

@@ -749,7 +749,7 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                             path_active = true;
                             bounce = true;
                         } else {
-                            if (work) atomicAdd(&pixel_work[px], work);
+                            if (pixel_work && work) atomicAdd(&pixel_work[px], work);
                             has_px = false;
                         }
                     }
@@ -1449,12 +1449,13 @@ static int lds_resident_threads(const pt_context *ctx, int *levels_out, size_t *
 }
 
 // Frames per kernel launch: the samples of one launch are staged as [frame][pixel] float4 and
-// folded into the images by k_accumulate; the staging buffer is capped at 1 GiB (2^26 paths
-// per launch; the wavefront queues take another 112 bytes per path).
-static uint32_t frames_per_launch(const pt_context *ctx, uint32_t count)
+// folded into the images by k_accumulate.  The staging buffer is capped at 4 GiB (2^28 paths per
+// launch), and at 1 GiB (2^26 paths) for the wavefront schedule, whose queues take another 112
+// bytes per path and index paths with 32 bits.
+static uint32_t frames_per_launch(const pt_context *ctx, uint32_t count, bool wavefront)
 {
     const size_t per_frame = (size_t)ctx->W * ctx->H * sizeof(float4);
-    size_t cap = ((size_t)1 << 30) / per_frame;
+    size_t cap = ((size_t)(wavefront ? 1 : 4) << 30) / per_frame;
     if (cap < 1) cap = 1;
     return (uint32_t)(count < cap ? count : cap);
 }
@@ -1475,7 +1476,9 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
     if (const char *e = getenv("PTAMD_LDS_THREADS")) { int t = atoi(e); if (t >= 64 && t <= threads) { threads = (t / 64) * 64; lds_bytes = (size_t)ctx->n * 48 + (size_t)levels * 4 * threads; } }
     static const bool no_order = getenv("PTAMD_NO_ORDER") && atoi(getenv("PTAMD_NO_ORDER"));
 
-    const uint32_t per_launch = frames_per_launch(ctx, count);
+    bool wavefront = threads >= 256 && ctx->schedule == PT_SCHEDULE_WAVEFRONT;
+    if (const char *e = getenv("PTAMD_MEGAKERNEL")) wavefront = threads >= 256 && !atoi(e);   // A/B runs
+    const uint32_t per_launch = frames_per_launch(ctx, count, wavefront);
     if (ctx->samples_frames < per_launch) {
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_samples) (void)hipFree(ctx->d_samples);
@@ -1484,8 +1487,6 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
         PT_HIP(ctx, hipMalloc((void **)&ctx->d_samples, (size_t)per_launch * npix * sizeof(float4)));
         ctx->samples_frames = per_launch;
     }
-    bool wavefront = threads >= 256 && ctx->schedule == PT_SCHEDULE_WAVEFRONT;
-    if (const char *e = getenv("PTAMD_MEGAKERNEL")) wavefront = threads >= 256 && !atoi(e);   // A/B runs
     if (wavefront && ctx->wf_paths < (size_t)per_launch * npix) {
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int k = 0; k < 2; k++) { if (ctx->d_wf_queue[k]) (void)hipFree(ctx->d_wf_queue[k]); ctx->d_wf_queue[k] = nullptr; }
@@ -1562,6 +1563,11 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             if (chunk > cnt) chunk = cnt;
             chunk = (cnt + (cnt + chunk - 1) / chunk - 1) / ((cnt + chunk - 1) / chunk);
             if (const char *e = getenv("PTAMD_CHUNK")) { chunk = (unsigned long long)atoi(e); if (chunk < 1) chunk = 1; if (chunk > cnt) chunk = cnt; }
+            // With few items per lane the launch ends ragged unless the expensive pixels go first; with
+            // many, image order (neighbouring pixels, similar paths in a wave) is the better order.
+            const unsigned long long items = (unsigned long long)npix * ((cnt + chunk - 1) / chunk);
+            const bool ordered = !no_order && items < 32ull * lanes;
+            if (!ordered) ctx->order_valid = false;
             PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
             hipLaunchKernelGGL(k_path_seeds, dim3((unsigned)ctx->num_cus * 16u), dim3(256), 0, ctx->stream, ctx->W, (unsigned)npix, cnt,
                                seeds, ctx->d_samples);
@@ -1570,7 +1576,8 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             hipLaunchKernelGGL((k_trace_lds<C>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
                 ctx->W, ctx->H, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, seeds, \
                 ctx->d_samples, ctx->d_counters, ctx->d_work, \
-                ctx->order_valid ? ctx->d_ovals[0] : (const uint32_t *)nullptr, ctx->d_pixel_work, (uint32_t)chunk, tune); } while (0)
+                ctx->order_valid ? ctx->d_ovals[0] : (const uint32_t *)nullptr, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, \
+                (uint32_t)chunk, tune); } while (0)
             if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream));
             if (ctx->detailed) PT_LAUNCH_LDS(true); else PT_LAUNCH_LDS(false);
 #undef PT_LAUNCH_LDS
@@ -1578,7 +1585,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             PT_HIP(ctx, hipGetLastError());
             // queue order of the next launch from the decaying per-pixel iteration counts (about
             // eight launches of at most 2^12 iterations per frame), reduced to 16 bits
-            if (!no_order) {
+            if (ordered) {
                 const unsigned long long top = (unsigned long long)cnt << 15;
                 int bits = 0;
                 while ((top >> bits) != 0) bits++;

@@ -5,8 +5,9 @@ The path has no other exchange step: every (pixel, frame) sample depends only on
 and that frame's seed, so ranks never talk while tracing (weak scaling: per-GPU work is fixed).
 """
 
-FRAMES_PER_BLOCK = 32     # one full cycle of the shader's frame-index stratification
-                          # (framecount & 1, (framecount >> 1) & 3, (framecount >> 3) & 3)
+FRAMES_PER_BLOCK = 128    # four full cycles of the shader's frame-index stratification
+                          # (framecount & 1, (framecount >> 1) & 3, (framecount >> 3) & 3: period 32);
+                          # one launch per block: the longer the launch, the smaller the share of its tail
 
 
 def block_frames(step, rank, world_size, frames_per_block=FRAMES_PER_BLOCK):
