@@ -1464,7 +1464,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
 {
     SceneView sv;
     if (int rc = make_view(ctx, sv)) return rc;
-    Tuning tune = {16, 12};
+    Tuning tune = {20, 16};
     if (const char *e = getenv("PTAMD_REFILL_T")) tune.refill_t = atoi(e);
     if (const char *e = getenv("PTAMD_LEAF_T")) tune.leaf_t = atoi(e);
     const bool lin = (mode == PT_ACCUM_LINEAR);
