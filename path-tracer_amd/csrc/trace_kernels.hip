@@ -11,7 +11,7 @@
 // and no fast-math.  Work is VALU / latency bound on L2-resident trees; there
 // is no dense contraction here, so no matrix-core use.
 //
-// Execution shape.  Every path writes its radiance sample into a [frame][pixel]
+// Execution shape.  Every path writes its radiance sample into a [pixel][frame]
 // staging buffer and k_accumulate folds the frames of a launch into the images
 // in frame order, so which lane traces which path never enters a result.
 //   k_trace      any tree (nodes in global memory): one lane per pixel, a wave
@@ -338,7 +338,6 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, in
     const bool in_image = (x < W && y < H);
     const size_t p = in_image ? (size_t)y * (size_t)W + (size_t)x : 0;
     const pt_Material *mats = sc.cb->mats;
-    const size_t npix = (size_t)W * (size_t)H;
 
     // per-pixel constants of the first bounce (ray_tracing.hlsl:349-367)
     const uchar4 dif8 = reinterpret_cast<const uchar4 *>(diffuse_tex)[p];
@@ -361,7 +360,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, in
 
     // the radiance sample of local frame fl (ray_tracing.hlsl:396-411: `multi` or black)
     auto emit = [&](const pt_f3 &color, uint32_t fl) {
-        samples[(size_t)fl * npix + p] = make_float4(color.x, color.y, color.z, 1.0f);
+        samples[p * count + fl] = make_float4(color.x, color.y, color.z, 1.0f);
     };
 
     // lane state
@@ -547,7 +546,7 @@ __global__ __launch_bounds__(256) void k_path_seeds(int W, unsigned npix, uint32
 {
     const size_t total = (size_t)npix * count;
     for (size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x; slot < total; slot += (size_t)gridDim.x * 256) {
-        const unsigned fl = (unsigned)(slot / npix), px = (unsigned)(slot - (size_t)fl * npix);
+        const unsigned px = (unsigned)(slot / count), fl = (unsigned)(slot - (size_t)px * count);
         const unsigned y = px / (unsigned)W, x = px - y * (unsigned)W;
         // ray_tracing.hlsl:410: uint(launchIndex.x + launchIndex.y * viewportDims.x), in float
         const uint32_t pixel_id = (uint32_t)((float)x + (float)y * (float)W);
@@ -646,7 +645,7 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
 
     // the radiance sample of local frame fl (ray_tracing.hlsl:396-411: `multi` or black)
     auto emit = [&](const pt_f3 &color, uint32_t fl) {
-        samples[(size_t)fl * npix + px] = make_float4(color.x, color.y, color.z, 1.0f);
+        samples[(size_t)px * count + fl] = make_float4(color.x, color.y, color.z, 1.0f);
     };
 
     for (;;) {
@@ -742,7 +741,7 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                             // new path of frame f (ray_tracing.hlsl:348-370, 410)
                             cnt.paths++;
                             // rand_init(pixel, seed of the frame), left in the path's sample slot by k_path_seeds
-                            seed = __float_as_uint(samples[(size_t)f * npix + px].w);
+                            seed = __float_as_uint(samples[(size_t)px * count + f].w);
                             multi = multi0;
                             itr = 1;
                             ray.o = hit_pos;
@@ -910,7 +909,7 @@ constexpr int WF_SEGS = 64;             // = lanes of a wave: one lane inspects 
 constexpr int WF_CSTRIDE = 32;          // words between counters (128 bytes)
 struct PathRec {                 // 48 bytes
     float ox, oy, oz; uint32_t seed;
-    float dx, dy, dz; uint32_t slot;      // slot = local frame * pixels + pixel: the sample to write
+    float dx, dy, dz; uint32_t slot;      // slot = pixel * frames of the launch + local frame: the sample to write
     float mx, my, mz; int itr;
 };
 struct HitRec { float t; int prim; float bx, by; };   // prim < 0: no hit
@@ -957,7 +956,7 @@ __global__ __launch_bounds__(256) void k_wf_first(SceneView sc, int W, int H,
         bool cont = false;
         PathRec rec = {};
         if (slot < total) {
-            const unsigned fl = slot / npix, px = slot - fl * npix;
+            const unsigned px = slot / count, fl = slot - px * count;
             const float4 nrm4 = normal_tex[px];
             const int matid0 = __float_as_int(nrm4.w) - 1;              // asint(normal.w) - 1
             cnt.paths++;
@@ -997,7 +996,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(SceneView sc, const PathRec *_
                                                   const unsigned *__restrict__ count_in,
                                                   PathRec *__restrict__ queue_out, unsigned *__restrict__ count_out,
                                                   unsigned seg_size,
-                                                  float4 *__restrict__ samples, uint32_t first_frame, unsigned npix)
+                                                  float4 *__restrict__ samples, uint32_t first_frame, uint32_t count)
 {
     // blockIdx.y = segment; the blocks of a segment stride over its records
     const unsigned seg = blockIdx.y;
@@ -1036,7 +1035,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(SceneView sc, const PathRec *_
                     const float bx = h.z, by = h.w, bz = 1 - bx - by;
                     const pt_f3 A = pt_mk3(s0.x, s0.y, s0.z), B = pt_mk3(s1.x, s1.y, s1.z), C = pt_mk3(s2.x, s2.y, s2.z);
                     const pt_f3 normal = pt_add3(pt_add3(pt_scale3(A, bz), pt_scale3(B, bx)), pt_scale3(C, by));
-                    const uint32_t framecount = first_frame + slot / npix;
+                    const uint32_t framecount = first_frame + slot % count;
                     pt_f3 direction;
                     if (get_bounce(mats, framecount, d, normal, __float_as_int(s0.w), multi, direction, seed)) {
                         cont = true;
@@ -1238,7 +1237,7 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
     flush_counters(cnt, counters, COUNT);
 }
 
-// Folds the samples of `count` frames (layout [frame][pixel]) into the images, frame by frame
+// Folds the samples of `count` frames (layout [pixel][frame]) into the images, frame by frame
 // in order.  LITERAL: ray_tracing.hlsl:412-419 on `output` / `old` plus the UNORM8 copy;
 // LINEAR: running float sum, alpha counts samples.
 template <bool LINEAR>
@@ -1252,7 +1251,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const float4 *__restrict__ s
     float4 acc = LINEAR ? linear[p] : output[p];
     const float inv_gamma = 1 / 2.2f;
     for (uint32_t k = 0; k < count; k++) {
-        const float4 c = samples[(size_t)k * npix + p];
+        const float4 c = samples[p * count + k];
         if (LINEAR) {
             acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += 1.0f;
         } else {
@@ -1448,7 +1447,7 @@ static int lds_resident_threads(const pt_context *ctx, int *levels_out, size_t *
     return (int)t;
 }
 
-// Frames per kernel launch: the samples of one launch are staged as [frame][pixel] float4 and
+// Frames per kernel launch: the samples of one launch are staged as [pixel][frame] float4 (a lane writes the frames of its item side by side) and
 // folded into the images by k_accumulate.  The staging buffer is capped at 4 GiB (2^28 paths per
 // launch), and at 1 GiB (2^26 paths) for the wavefront schedule, whose queues take another 112
 // bytes per path and index paths with 32 bits.
@@ -1538,7 +1537,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
                     hipLaunchKernelGGL((k_wf_extend<false>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted,
                                        levels, qin, qcount + d * per_depth, seg_size, hits, qhead + d * per_depth, ctx->d_counters, wt);
                 hipLaunchKernelGGL(k_wf_shade, sgrid, dim3(256), 0, ctx->stream, sv, qin, hits, qcount + d * per_depth, qout,
-                                   qcount + (d + 1) * per_depth, seg_size, ctx->d_samples, first, (unsigned)npix);
+                                   qcount + (d + 1) * per_depth, seg_size, ctx->d_samples, first, cnt);
             }
             if (ev_end) PT_HIP(ctx, hipEventRecord(ev_end, ctx->stream));
             PT_HIP(ctx, hipGetLastError());

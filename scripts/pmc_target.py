@@ -1,5 +1,5 @@
 """Small torch-free target for rocprofv3 counter passes: `trace` (scene04 1162x1008, 3 launches of
-32 frames) or `build` (10M-triangle soup, 3 builds)."""
+128 frames, the benchmark's step) or `build` (10M-triangle soup, 3 builds)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +13,7 @@ if mode == "trace":
     ctx.build(); ctx.resize(1162, 1008)
     ctx.primary_hits(ptamd.default_camera(), ptamd.albedo_table(g["mat_table"][:, 0:3], True))
     for s in range(3):
-        ctx.trace_frames(32 * s, ptamd.frame_seeds(1, 32 * s, 32), ptamd.PT_ACCUM_LINEAR)
+        ctx.trace_frames(128 * s, ptamd.frame_seeds(1, 128 * s, 128), ptamd.PT_ACCUM_LINEAR)
     ctx.synchronize()
     print(ctx.counters())
 else:
