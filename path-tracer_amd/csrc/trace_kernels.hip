@@ -47,6 +47,10 @@ struct Ray {
     pt_f3 d; float t_max;
 };
 
+// wave64 vote straight from the comparison's lane mask (the int-predicate form first turns
+// the mask into 0/1 per lane and compares again: two vector instructions per vote)
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 struct LaneCounters {
     unsigned paths = 0, rays = 0, node_visits = 0, box_tests = 0, tri_tests = 0;
 };
@@ -388,8 +392,8 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, in
     for (;;) {
         // ------------------------------------------------------------ refill
         const bool need = alive && cur == IDLE;
-        const unsigned long long need_mask = __ballot(need);
-        const unsigned long long trav_mask = __ballot(alive && cur != IDLE);
+        const unsigned long long need_mask = ballot64(need);
+        const unsigned long long trav_mask = ballot64(alive && cur != IDLE);
         if (need_mask == 0 && trav_mask == 0) break;
         if (need_mask != 0 && (__popcll(need_mask) >= REFILL_T || trav_mask == 0)) {
             if (need) {
@@ -466,9 +470,9 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, in
         // --------------------------------------------------------- traversal
         for (;;) {
             const bool trav = alive && cur != IDLE;
-            const unsigned long long tm = __ballot(trav);
+            const unsigned long long tm = ballot64(trav);
             if (tm == 0) break;
-            if (__popcll(__ballot(alive && cur == IDLE)) >= REFILL_T) break;
+            if (__popcll(ballot64(alive && cur == IDLE)) >= REFILL_T) break;
             if (trav && cur >= 0) {
                 const float4 *w = reinterpret_cast<const float4 *>(&sc.wide[cur]);
                 const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
@@ -487,8 +491,8 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, in
                 }
             }
             const bool at_leaf = trav && cur < 0 && cur != POP;
-            const unsigned long long leaf_mask = __ballot(at_leaf);
-            if (leaf_mask != 0 && (__popcll(leaf_mask) >= LEAF_T || __ballot(trav && cur >= 0) == 0)) {
+            const unsigned long long leaf_mask = ballot64(at_leaf);
+            if (leaf_mask != 0 && (__popcll(leaf_mask) >= LEAF_T || ballot64(trav && cur >= 0) == 0)) {
                 if (at_leaf) {
                     const int prim = ~cur;
                     const float4 *tp = reinterpret_cast<const float4 *>(&sc.tri[prim]);
@@ -580,7 +584,11 @@ __global__ __launch_bounds__(256) void k_path_seeds(int W, unsigned npix, uint32
 // the previous launches' per-pixel iteration counts), so the launch ends on cheap
 // items.  Items only decide who computes a sample, never its value.
 // ---------------------------------------------------------------------------
-constexpr int K_POP = -1, K_IDLE = -2;
+// lane states below the tree levels (cur_k >= 1: at an internal node of that level, 0: at a leaf):
+// K_POP: take a pending child; K_IDLE: holds an item, its ray is finished (or not started);
+// K_NOITEM: holds no item.  One register and single comparisons, so that the wave votes of the
+// loop control are the comparison masks themselves.
+constexpr int K_POP = -1, K_IDLE = -2, K_NOITEM = -3;
 
 template <bool COUNT>
 __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect *__restrict__ tri_sorted, int levels,
@@ -621,8 +629,7 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
     unsigned q_next = 0, q_end = 0;
     bool exhausted = false;
 
-    // per-item state (has_px: the lane holds an item)
-    bool has_px = false;
+    // per-item state
     unsigned px = 0;
     int matid0 = 0;
     pt_f3 hit_pos = pt_mk3(0, 0, 0), multi0 = pt_mk3(0, 0, 0), view0 = pt_mk3(0, 0, 0), normal0 = pt_mk3(0, 0, 0);
@@ -630,7 +637,7 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
     uint32_t work = 0;                  // traversal iterations this item has occupied its lane
     // per-path / per-ray state
     bool path_active = false;
-    int cur_k = K_IDLE, cur_s = 0, cur_id = 0;
+    int cur_k = K_NOITEM, cur_s = 0, cur_id = 0;
     unsigned pending = 0;
     uint32_t seed = 0;
     int itr = 1;
@@ -648,18 +655,24 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
         samples[(size_t)px * count + fl] = make_float4(color.x, color.y, color.z, 1.0f);
     };
 
+    // lanes to serve in a refill: K_IDLE always, K_NOITEM while the queue has items
+    // ((cur_k - K_NOITEM) in [lo, 1] as one unsigned comparison)
+    auto need_vote = [&]() {
+        const unsigned lo = exhausted ? 1u : 0u;
+        return ballot64((unsigned)(cur_k - K_NOITEM) - lo < 2u - lo);
+    };
+
     for (;;) {
         // ------------------------------------------------------------ refill
-        const bool need = (has_px && cur_k == K_IDLE) || (!has_px && !exhausted);
-        const unsigned long long need_mask = __ballot(need);
-        const unsigned long long trav_mask = __ballot(has_px && cur_k >= K_POP);
+        const unsigned long long need_mask = need_vote();
+        const unsigned long long trav_mask = ballot64(cur_k >= K_POP);
         if (need_mask == 0 && trav_mask == 0) break;
         if (need_mask != 0 && (__popcll(need_mask) >= REFILL_T || trav_mask == 0)) {
             if (COUNT) sched[5]++;
             for (int pass = 0; pass < 2; pass++) {
                 // ---- take new pixels
-                bool want = !has_px && !exhausted;
-                unsigned long long wm = __ballot(want);
+                bool want = cur_k == K_NOITEM && !exhausted;
+                unsigned long long wm = ballot64(want);
                 while (wm != 0) {
                     if (q_next == q_end) {
                         unsigned base = 0;
@@ -692,17 +705,16 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                             normal0 = pt_normalize3(pt_mk3(nrm4.x, nrm4.y, nrm4.z));
                             path_active = false;
                             cur_k = K_IDLE;
-                            has_px = true;
                             want = false;
                         }
                     }
                     q_next += min((unsigned)__popcll(wm), avail);
-                    wm = __ballot(want);
+                    wm = ballot64(want);
                 }
                 // ---- shade finished rays, continue / end / start paths: ONE pass, so that the
                 // expensive parts (first-bounce set-up, get_bounce, ray set-up) run once per round for
                 // all idle lanes together; a lane left without a ray is served by the next round
-                if (has_px && cur_k == K_IDLE) {
+                if (cur_k == K_IDLE) {
                     pt_f3 direction;
                     bool cont = false, bounce = false;
                     pt_f3 b_view = view0, b_normal = normal0;
@@ -749,7 +761,7 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                             bounce = true;
                         } else {
                             if (pixel_work && work) atomicAdd(&pixel_work[px], work);
-                            has_px = false;
+                            cur_k = K_NOITEM;
                         }
                     }
                     if (bounce) {
@@ -778,20 +790,20 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                         }
                     }
                 }
-                if (__ballot(!has_px && !exhausted) == 0) break;
+                if (exhausted || ballot64(cur_k == K_NOITEM) == 0) break;
             }
         }
         // --------------------------------------------------------- traversal
         for (;;) {
-            const bool trav = has_px && cur_k >= K_POP;
-            if (__ballot(trav) == 0) break;
-            if (__popcll(__ballot((has_px && cur_k == K_IDLE) || (!has_px && !exhausted))) >= REFILL_T) break;
+            const bool trav = cur_k >= K_POP;
+            if (ballot64(trav) == 0) break;
+            if (__popcll(need_vote()) >= REFILL_T) break;
             if (COUNT) {
                 sched[0]++;
-                sched[1] += __popcll(__ballot(trav && cur_k >= 1));
-                sched[4] += __popcll(__ballot(trav && cur_k == 0));                     // waiting at a leaf
-                sched[6] += __popcll(__ballot(has_px && cur_k == K_IDLE));             // waiting for a refill
-                sched[7] += __popcll(__ballot(!has_px));                               // no pixel (queue empty)
+                sched[1] += __popcll(ballot64(trav && cur_k >= 1));
+                sched[4] += __popcll(ballot64(trav && cur_k == 0));                     // waiting at a leaf
+                sched[6] += __popcll(ballot64(cur_k == K_IDLE));                       // waiting for a refill
+                sched[7] += __popcll(ballot64(cur_k == K_NOITEM));                     // no item (queue empty)
             }
             work += trav ? 1u : 0u;
             if (trav && cur_k >= 1) {
@@ -818,8 +830,8 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                 }
             }
             const bool at_leaf = trav && cur_k == 0;
-            const unsigned long long leaf_mask = __ballot(at_leaf);
-            if (leaf_mask != 0 && (__popcll(leaf_mask) >= LEAF_T || __ballot(trav && cur_k >= 1) == 0)) {
+            const unsigned long long leaf_mask = ballot64(at_leaf);
+            if (leaf_mask != 0 && (__popcll(leaf_mask) >= LEAF_T || ballot64(trav && cur_k >= 1) == 0)) {
                 if (COUNT) { sched[2]++; sched[3] += __popcll(leaf_mask); }
                 if (at_leaf) {
                     const float4 *tp = reinterpret_cast<const float4 *>(&tri_sorted[cur_s]);
@@ -920,7 +932,7 @@ constexpr int WF_MAX_RAYS = MAX_ITR * 3 - 1;           // rays of the longest pa
 __device__ __forceinline__ void wf_append(bool keep, const PathRec &rec, PathRec *__restrict__ queue,
                                           unsigned *__restrict__ count)
 {
-    const unsigned long long m = __ballot(keep);
+    const unsigned long long m = ballot64(keep);
     if (m == 0) return;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -1064,7 +1076,7 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
     const int lane = threadIdx.x & 63;
     // lane k looks at segment k; an empty queue ends the launch before the tree is loaded
     const unsigned my_seg_count = count_in[lane * WF_CSTRIDE];
-    if (__ballot(my_seg_count != 0) == 0) return;
+    if (ballot64(my_seg_count != 0) == 0) return;
     const int n = sc.n;
     const int nthreads = blockDim.x;
     float *stack = reinterpret_cast<float *>(lds_nodes + 3 * n) + threadIdx.x;   // level L at stack[(L-1) * nthreads]
@@ -1097,8 +1109,8 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
     for (;;) {
         // ------------------------------------------------------------ refill
         const bool need = cur_k == K_IDLE && (have || !exhausted);
-        const unsigned long long need_mask = __ballot(need);
-        const unsigned long long trav_mask = __ballot(cur_k >= K_POP);
+        const unsigned long long need_mask = ballot64(need);
+        const unsigned long long trav_mask = ballot64(cur_k >= K_POP);
         if (need_mask == 0 && trav_mask == 0) break;
         if (need_mask != 0 && (__popcll(need_mask) >= REFILL_T || trav_mask == 0)) {
             if (cur_k == K_IDLE && have) {
@@ -1107,7 +1119,7 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
                 have = false;
             }
             bool want = cur_k == K_IDLE && !exhausted;
-            unsigned long long wm = __ballot(want);
+            unsigned long long wm = ballot64(want);
             while (wm != 0) {
                 if (q_next == q_end) {
                     // 64 records of the current segment; when it has none left, move to the next
@@ -1123,7 +1135,7 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
                             break;
                         }
                         const unsigned h = __hip_atomic_load(&heads[lane * WF_CSTRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned long long open = __ballot(h < my_seg_count);
+                        const unsigned long long open = ballot64(h < my_seg_count);
                         if (open == 0) { exhausted = true; break; }
                         const unsigned long long above = (seg == 63) ? 0ull : (open & (~0ull << (seg + 1)));
                         seg = __ffsll((long long)(above ? above : open)) - 1;
@@ -1153,14 +1165,14 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
                     want = false;
                 }
                 q_next += min((unsigned)__popcll(wm), avail);
-                wm = __ballot(want);
+                wm = ballot64(want);
             }
         }
         // --------------------------------------------------------- traversal
         for (;;) {
             const bool trav = cur_k >= K_POP;
-            if (__ballot(trav) == 0) break;
-            if (__popcll(__ballot(cur_k == K_IDLE && (have || !exhausted))) >= REFILL_T) break;
+            if (ballot64(trav) == 0) break;
+            if (__popcll(ballot64(cur_k == K_IDLE && (have || !exhausted))) >= REFILL_T) break;
             if (trav && cur_k >= 1) {
                 const float4 *w = lds_nodes + __umul24((unsigned)cur_id, 3u);   // 24-bit multiply: full rate
                 const float4 w0 = w[0], w1 = w[1], w2 = w[2];
@@ -1185,8 +1197,8 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
                 }
             }
             const bool at_leaf = trav && cur_k == 0;
-            const unsigned long long leaf_mask = __ballot(at_leaf);
-            if (leaf_mask != 0 && (__popcll(leaf_mask) >= LEAF_T || __ballot(trav && cur_k >= 1) == 0)) {
+            const unsigned long long leaf_mask = ballot64(at_leaf);
+            if (leaf_mask != 0 && (__popcll(leaf_mask) >= LEAF_T || ballot64(trav && cur_k >= 1) == 0)) {
                 if (at_leaf) {
                     const float4 *tp = reinterpret_cast<const float4 *>(&tri_sorted[cur_s]);
                     const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
