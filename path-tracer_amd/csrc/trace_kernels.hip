@@ -634,7 +634,8 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
     int matid0 = 0;
     pt_f3 hit_pos = pt_mk3(0, 0, 0), multi0 = pt_mk3(0, 0, 0), view0 = pt_mk3(0, 0, 0), normal0 = pt_mk3(0, 0, 0);
     uint32_t f = 0, f_end = 0;          // next local frame of the item, one past its last
-    uint32_t work = 0;                  // traversal iterations this item has occupied its lane
+    uint32_t work_start = 0;            // value of `iterations` when the lane took its item
+    uint32_t iterations = 0;            // wave-uniform: traversal iterations of this wave so far
     // per-path / per-ray state
     bool path_active = false;
     int cur_k = K_NOITEM, cur_s = 0, cur_id = 0;
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                         px = order ? order[slot] : slot;
                         f = (item - slot * chunks) * chunk;
                         f_end = min(f + chunk, count);
-                        work = 0;
+                        work_start = iterations;
                         const uchar4 dif8 = reinterpret_cast<const uchar4 *>(diffuse_tex)[px];
                         const float4 nrm4 = normal_tex[px];
                         const float4 pos4 = world_tex[px];
@@ -760,7 +761,8 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                             path_active = true;
                             bounce = true;
                         } else {
-                            if (pixel_work && work) atomicAdd(&pixel_work[px], work);
+                            // cost of the item = traversal iterations its lane was occupied
+                            if (pixel_work && iterations != work_start) atomicAdd(&pixel_work[px], iterations - work_start);
                             cur_k = K_NOITEM;
                         }
                     }
@@ -800,13 +802,13 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
             if (__popcll(need_vote()) >= REFILL_T) break;
             if (COUNT) {
                 sched[0]++;
-                sched[1] += __popcll(ballot64(trav && cur_k >= 1));
-                sched[4] += __popcll(ballot64(trav && cur_k == 0));                     // waiting at a leaf
+                sched[1] += __popcll(ballot64(cur_k >= 1));
+                sched[4] += __popcll(ballot64(cur_k == 0));                     // waiting at a leaf
                 sched[6] += __popcll(ballot64(cur_k == K_IDLE));                       // waiting for a refill
                 sched[7] += __popcll(ballot64(cur_k == K_NOITEM));                     // no item (queue empty)
             }
-            work += trav ? 1u : 0u;
-            if (trav && cur_k >= 1) {
+            iterations++;
+            if (cur_k >= 1) {                       // only traversing lanes have cur_k >= K_POP
                 const float4 *w = lds_nodes + __umul24((unsigned)cur_id, 3u);   // 24-bit multiply: full rate
                 const float4 w0 = w[0], w1 = w[1], w2 = w[2];
                 const float lmn[3] = {w0.x, w0.y, w0.z}, lmx[3] = {w0.w, w1.x, w1.y};
@@ -829,9 +831,9 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                     cur_k = K_POP;
                 }
             }
-            const bool at_leaf = trav && cur_k == 0;
+            const bool at_leaf = cur_k == 0;
             const unsigned long long leaf_mask = ballot64(at_leaf);
-            if (leaf_mask != 0 && (__popcll(leaf_mask) >= LEAF_T || ballot64(trav && cur_k >= 1) == 0)) {
+            if (leaf_mask != 0 && (__popcll(leaf_mask) >= LEAF_T || ballot64(cur_k >= 1) == 0)) {
                 if (COUNT) { sched[2]++; sched[3] += __popcll(leaf_mask); }
                 if (at_leaf) {
                     const float4 *tp = reinterpret_cast<const float4 *>(&tri_sorted[cur_s]);
@@ -861,7 +863,7 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                     cur_k = K_POP;
                 }
             }
-            if (trav && cur_k == K_POP) {
+            if (cur_k == K_POP) {
                 // one pending child per iteration; an entry whose entry distance no longer passes
                 // the distance test is dropped and the lane tries again next iteration
                 if (pending == 0) {
@@ -1173,7 +1175,7 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
             const bool trav = cur_k >= K_POP;
             if (ballot64(trav) == 0) break;
             if (__popcll(ballot64(cur_k == K_IDLE && (have || !exhausted))) >= REFILL_T) break;
-            if (trav && cur_k >= 1) {
+            if (cur_k >= 1) {                       // only traversing lanes have cur_k >= K_POP
                 const float4 *w = lds_nodes + __umul24((unsigned)cur_id, 3u);   // 24-bit multiply: full rate
                 const float4 w0 = w[0], w1 = w[1], w2 = w[2];
                 const float lmn[3] = {w0.x, w0.y, w0.z}, lmx[3] = {w0.w, w1.x, w1.y};
@@ -1196,9 +1198,9 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
                     cur_k = K_POP;
                 }
             }
-            const bool at_leaf = trav && cur_k == 0;
+            const bool at_leaf = cur_k == 0;
             const unsigned long long leaf_mask = ballot64(at_leaf);
-            if (leaf_mask != 0 && (__popcll(leaf_mask) >= LEAF_T || ballot64(trav && cur_k >= 1) == 0)) {
+            if (leaf_mask != 0 && (__popcll(leaf_mask) >= LEAF_T || ballot64(cur_k >= 1) == 0)) {
                 if (at_leaf) {
                     const float4 *tp = reinterpret_cast<const float4 *>(&tri_sorted[cur_s]);
                     const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
@@ -1226,7 +1228,7 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
                     cur_k = K_POP;
                 }
             }
-            if (trav && cur_k == K_POP) {
+            if (cur_k == K_POP) {
                 // one pending child per iteration; an entry whose entry distance no longer passes
                 // the distance test is dropped and the lane tries again next iteration
                 if (pending == 0) {
