@@ -623,8 +623,8 @@ int pt_get_counters(pt_context *ctx, pt_counters *out)
     out->paths = h.paths; out->rays = h.rays; out->node_visits = h.node_visits;
     out->box_tests = h.box_tests; out->tri_tests = h.tri_tests;
     if (getenv("PTAMD_PRINT_SCHED"))
-        fprintf(stderr, "sched: iters %llu int_lanes %llu leaf_rounds %llu leaf_lanes %llu at_leaf_wait %llu refills %llu idle_wait %llu no_pixel %llu\n",
-                h.sched[0], h.sched[1], h.sched[2], h.sched[3], h.sched[4], h.sched[5], h.sched[6], h.sched[7]);
+        fprintf(stderr, "sched: iters %llu int_lanes %llu leaf_rounds %llu leaf_lanes %llu at_leaf_wait %llu refills %llu idle_wait %llu no_pixel %llu refill_ticks %llu trav_ticks %llu\n",
+                h.sched[0], h.sched[1], h.sched[2], h.sched[3], h.sched[4], h.sched[5], h.sched[6], h.sched[7], h.sched[8], h.sched[9]);
     return PT_OK;
 }
 

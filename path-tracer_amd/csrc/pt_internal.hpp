@@ -55,7 +55,7 @@ struct DevCounters {
     // wave-scheduling statistics of the instrumented trace kernel (diagnostics only):
     // iterations, lanes expanding a node, triangle-test rounds, lanes testing, lanes waiting at
     // a leaf, refill rounds, lanes waiting for a refill, lanes without a pixel
-    unsigned long long sched[8];
+    unsigned long long sched[10];     // + clock ticks of a wave inside refill rounds, inside the traversal loop
 };
 
 constexpr int PT_SORT_THREADS = 256;

@@ -175,26 +175,37 @@ __device__ __forceinline__ bool traverse(const SceneView &sc, const Ray &ray, ui
     }
 }
 
-// ray_tracing.hlsl:249-346
-__device__ __forceinline__ bool get_bounce(const pt_Material *__restrict__ mats, uint32_t framecount,
+// The four quotients of getBounce that depend on the material alone (ray_tracing.hlsl:263 nc/nt,
+// :284 R0, :303 ks.x/(tr+ks.x+kd.x), :307 1/ns), evaluated with the shader's own float expressions.
+__device__ __forceinline__ float4 material_quotients(const float4 m0, const float4 m1, const float4 m2)
+{
+    const float ns = m0.y, tr = m0.z, ni = m0.w;
+    const float base = tr + m2.x + m1.x;
+    const float a = ni - 1.f, b = ni + 1.f;
+    return make_float4(1 / ns, m2.x / base, 1.f / ni, a * a / (b * b));
+}
+
+// ray_tracing.hlsl:249-346.  `mats` = 3 float4 per material (pt_Material); `matq` = one
+// material_quotients record per material, or null to evaluate them here.
+__device__ __forceinline__ bool get_bounce(const float4 *mats, const float4 *matq, uint32_t framecount,
                                            const pt_f3 view_dir, const pt_f3 normal, int id,
                                            pt_f3 &multi, pt_f3 &direction, uint32_t &seed)
 {
     direction = pt_mk3(0, 0, 0);
-    const float4 *mp = reinterpret_cast<const float4 *>(&mats[id]);
+    const float4 *mp = mats + 3 * id;
     const float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
     const float ke = m0.x, ns = m0.y, tr = m0.z, ni = m0.w;
     const float rand_mat = rand_next(seed);
-    const float base = tr + m2.x + m1.x;
     if (ke > 0) {
         multi = pt_mul3(multi, pt_mk3(ke, ke, ke));
         return false;
     }
     if (tr > 0) {
+        const float4 mq = matq ? matq[id] : material_quotients(m0, m1, m2);
         const float cosv = pt_dot3(normal, view_dir);
-        const float nc = 1.f, nt = ni;
-        float nnt = nc / nt;
-        if (cosv > 0) nnt = nt / nc;
+        const float nt = ni;
+        float nnt = mq.z;                    // nc / nt, nc = 1
+        if (cosv > 0) nnt = nt;              // nt / nc
         const float ddn = fabsf(cosv);
         const float cos2t = 1.f - nnt * nnt * (1.f - ddn * ddn);
         if (cos2t < 0.0f) {
@@ -208,8 +219,7 @@ __device__ __forceinline__ bool get_bounce(const pt_Material *__restrict__ mats,
             const float k = -cosv * nnt + sqrtf(cos2t);
             direction = pt_normalize3(pt_add3(pt_scale3(view_dir, nnt), pt_scale3(normal, k)));
         }
-        const float a = nt - nc, b = nt + nc;
-        const float R0 = a * a / (b * b);
+        const float R0 = mq.w;               // (nt - nc)^2 / (nt + nc)^2
         const float c = 1 - ddn;
         const float Re = R0 + (1 - R0) * c * c * c * c * c;
         const float Tr = 1 - Re;
@@ -224,10 +234,11 @@ __device__ __forceinline__ bool get_bounce(const pt_Material *__restrict__ mats,
         }
         return true;
     }
-    if (ns > 1 && rand_mat < m2.x / base) {
+    const float4 mq = matq ? matq[id] : material_quotients(m0, m1, m2);
+    if (ns > 1 && rand_mat < mq.y) {
         direction = pt_reflect3(view_dir, normal);
         const float r1 = 2 * PT_MY_PI * ((framecount & 1) / 2.0f + rand_next(seed) / 2);
-        const float height = pt_powf((((framecount >> 1) & 3) / 4.0f + rand_next(seed) / 4), 1 / ns);
+        const float height = pt_powf((((framecount >> 1) & 3) / 4.0f + rand_next(seed) / 4), mq.x);
         const float r2s = sqrtf(1 - height * height);
         const pt_f3 w = direction;
         const pt_f3 u = pt_normalize3(pt_cross3(w, view_dir));
@@ -341,7 +352,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, in
     LaneCounters cnt;
     const bool in_image = (x < W && y < H);
     const size_t p = in_image ? (size_t)y * (size_t)W + (size_t)x : 0;
-    const pt_Material *mats = sc.cb->mats;
+    const float4 *mats = reinterpret_cast<const float4 *>(sc.cb->mats);
 
     // per-pixel constants of the first bounce (ray_tracing.hlsl:349-367)
     const uchar4 dif8 = reinterpret_cast<const uchar4 *>(diffuse_tex)[p];
@@ -354,7 +365,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, in
     pt_f3 view0 = pt_mk3(0, 0, 0), normal0 = pt_mk3(0, 0, 0);
     if (in_image && !background) {
         const pt_f3 g_pos = pt_mk3(sc.cb->pos.v[0], sc.cb->pos.v[1], sc.cb->pos.v[2]);
-        if (mats[matid0].ns > 1) multi0 = pt_mk3(1, 1, 1);
+        if (mats[3 * matid0].y > 1) multi0 = pt_mk3(1, 1, 1);
         view0 = pt_normalize3(pt_sub3(hit_pos, g_pos));
         normal0 = pt_normalize3(pt_mk3(nrm4.x, nrm4.y, nrm4.z));
     }
@@ -421,7 +432,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, in
                             if (!ended) {
                                 const pt_f3 A = pt_mk3(s0.x, s0.y, s0.z), B = pt_mk3(s1.x, s1.y, s1.z), C = pt_mk3(s2.x, s2.y, s2.z);
                                 const pt_f3 new_normal = pt_add3(pt_add3(pt_scale3(A, hit_bz), pt_scale3(B, hit_bx)), pt_scale3(C, hit_by));
-                                if (get_bounce(mats, framecount, ray.d, new_normal, matid, multi, direction, seed)) cont = true;
+                                if (get_bounce(mats, nullptr, framecount, ray.d, new_normal, matid, multi, direction, seed)) cont = true;
                                 else color = multi;
                             }
                         }
@@ -438,7 +449,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, in
                         multi = multi0;
                         itr = 1;
                         ray.o = hit_pos;
-                        if (get_bounce(mats, framecount, view0, normal0, matid0, multi, direction, seed)) {
+                        if (get_bounce(mats, nullptr, framecount, view0, normal0, matid0, multi, direction, seed)) {
                             cont = true;
                             path_active = true;
                         } else {
@@ -603,13 +614,23 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                                                     const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
                                                     uint32_t chunk, Tuning tune)
 {
+    // LDS: node records (3 float4 each), the 16 materials (3 float4 each), their quotient records
+    // (1 float4 each), then the per-lane stacks
     extern __shared__ __attribute__((aligned(16))) float4 lds_nodes[];
     const int n = sc.n;
     const int nthreads = blockDim.x;
-    float *stack = reinterpret_cast<float *>(lds_nodes + 3 * n) + threadIdx.x;   // level L at stack[(L-1) * nthreads]
+    float4 *lds_mats = lds_nodes + 3 * n;
+    float4 *lds_matq = lds_mats + 3 * PT_MAX_MATERIALS;
+    float *stack = reinterpret_cast<float *>(lds_matq + PT_MAX_MATERIALS) + threadIdx.x;   // level L at stack[(L-1) * nthreads]
     for (int i = threadIdx.x; i < 3 * n; i += nthreads) {
         const int node = i / 3, part = i - 3 * node;
         lds_nodes[i] = reinterpret_cast<const float4 *>(&sc.wide[node])[part];
+    }
+    if (threadIdx.x < 3 * PT_MAX_MATERIALS)
+        lds_mats[threadIdx.x] = reinterpret_cast<const float4 *>(sc.cb->mats)[threadIdx.x];
+    if (threadIdx.x < PT_MAX_MATERIALS) {
+        const float4 *mp = reinterpret_cast<const float4 *>(sc.cb->mats) + 3 * threadIdx.x;
+        lds_matq[threadIdx.x] = material_quotients(mp[0], mp[1], mp[2]);
     }
     __syncthreads();
 
@@ -619,11 +640,11 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
     const unsigned npix = (unsigned)W * (unsigned)H;
     const unsigned chunks = (count + chunk - 1) / chunk;     // items per pixel
     const unsigned total_items = npix * chunks;
-    const pt_Material *mats = sc.cb->mats;
+    const float4 *mats = lds_mats;
     const pt_f3 g_pos = pt_mk3(sc.cb->pos.v[0], sc.cb->pos.v[1], sc.cb->pos.v[2]);
     const float root_mn[3] = {sc.root[0], sc.root[1], sc.root[2]}, root_mx[3] = {sc.root[3], sc.root[4], sc.root[5]};
     LaneCounters cnt;
-    unsigned long long sched[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long sched[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     // wave-uniform item queue
     unsigned q_next = 0, q_end = 0;
@@ -670,6 +691,7 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
         if (need_mask == 0 && trav_mask == 0) break;
         if (need_mask != 0 && (__popcll(need_mask) >= REFILL_T || trav_mask == 0)) {
             if (COUNT) sched[5]++;
+            const long long t_refill = COUNT ? (long long)__builtin_readcyclecounter() : 0;
             for (int pass = 0; pass < 2; pass++) {
                 // ---- take new pixels
                 bool want = cur_k == K_NOITEM && !exhausted;
@@ -701,7 +723,7 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                         } else {
                             hit_pos = pt_mk3(pos4.x, pos4.y, pos4.z);
                             multi0 = pt_mk3(dif8.x / 255.0f, dif8.y / 255.0f, dif8.z / 255.0f);
-                            if (mats[matid0].ns > 1) multi0 = pt_mk3(1, 1, 1);
+                            if (mats[3 * matid0].y > 1) multi0 = pt_mk3(1, 1, 1);
                             view0 = pt_normalize3(pt_sub3(hit_pos, g_pos));
                             normal0 = pt_normalize3(pt_mk3(nrm4.x, nrm4.y, nrm4.z));
                             path_active = false;
@@ -768,7 +790,7 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                     }
                     if (bounce) {
                         const uint32_t framecount = first_frame + f;
-                        if (get_bounce(mats, framecount, b_view, b_normal, b_mat, multi, direction, seed)) {
+                        if (get_bounce(mats, lds_matq, framecount, b_view, b_normal, b_mat, multi, direction, seed)) {
                             cont = true;
                         } else {
                             emit(multi, f);
@@ -794,7 +816,9 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                 }
                 if (exhausted || ballot64(cur_k == K_NOITEM) == 0) break;
             }
+            if (COUNT) sched[8] += (unsigned long long)((long long)__builtin_readcyclecounter() - t_refill);
         }
+        const long long t_trav = COUNT ? (long long)__builtin_readcyclecounter() : 0;
         // --------------------------------------------------------- traversal
         for (;;) {
             const bool trav = cur_k >= K_POP;
@@ -882,10 +906,11 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                 }
             }
         }
+        if (COUNT) sched[9] += (unsigned long long)((long long)__builtin_readcyclecounter() - t_trav);
     }
     flush_counters(cnt, counters, COUNT);
     if (COUNT && lane == 0) {
-        for (int k = 0; k < 8; k++) atomicAdd(&counters->sched[k], sched[k]);
+        for (int k = 0; k < 10; k++) atomicAdd(&counters->sched[k], sched[k]);
     }
 }
 
@@ -961,7 +986,7 @@ __global__ __launch_bounds__(256) void k_wf_first(SceneView sc, int W, int H,
 {
     const unsigned npix = (unsigned)W * (unsigned)H;
     const unsigned total = npix * count;
-    const pt_Material *mats = sc.cb->mats;
+    const float4 *mats = reinterpret_cast<const float4 *>(sc.cb->mats);
     const pt_f3 g_pos = pt_mk3(sc.cb->pos.v[0], sc.cb->pos.v[1], sc.cb->pos.v[2]);
     LaneCounters cnt;
     // whole waves iterate together so that wf_append sees every lane
@@ -981,14 +1006,14 @@ __global__ __launch_bounds__(256) void k_wf_first(SceneView sc, int W, int H,
                 const float4 pos4 = world_tex[px];
                 const pt_f3 hit_pos = pt_mk3(pos4.x, pos4.y, pos4.z);
                 pt_f3 multi = pt_mk3(dif8.x / 255.0f, dif8.y / 255.0f, dif8.z / 255.0f);
-                if (mats[matid0].ns > 1) multi = pt_mk3(1, 1, 1);
+                if (mats[3 * matid0].y > 1) multi = pt_mk3(1, 1, 1);
                 const pt_f3 view0 = pt_normalize3(pt_sub3(hit_pos, g_pos));
                 const pt_f3 normal0 = pt_normalize3(pt_mk3(nrm4.x, nrm4.y, nrm4.z));
                 // ray_tracing.hlsl:410: uint(launchIndex.x + launchIndex.y * viewportDims.x), in float
                 const uint32_t pixel_id = (uint32_t)((float)x + (float)y * (float)W);
                 uint32_t seed = rand_init(pixel_id, seeds[fl]);
                 pt_f3 direction;
-                if (get_bounce(mats, first_frame + fl, view0, normal0, matid0, multi, direction, seed)) {
+                if (get_bounce(mats, nullptr, first_frame + fl, view0, normal0, matid0, multi, direction, seed)) {
                     cont = true;
                     rec.ox = hit_pos.x; rec.oy = hit_pos.y; rec.oz = hit_pos.z; rec.seed = seed;
                     rec.dx = direction.x; rec.dy = direction.y; rec.dz = direction.z; rec.slot = slot;
@@ -1016,7 +1041,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(SceneView sc, const PathRec *_
     const unsigned seg = blockIdx.y;
     const unsigned total = count_in[seg * WF_CSTRIDE];
     const size_t seg_base = (size_t)seg * seg_size;
-    const pt_Material *mats = sc.cb->mats;
+    const float4 *mats = reinterpret_cast<const float4 *>(sc.cb->mats);
     for (unsigned base = blockIdx.x * 256u; base < total; base += gridDim.x * 256u) {
         const unsigned i = base + threadIdx.x;
         bool cont = false;
@@ -1051,7 +1076,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(SceneView sc, const PathRec *_
                     const pt_f3 normal = pt_add3(pt_add3(pt_scale3(A, bz), pt_scale3(B, bx)), pt_scale3(C, by));
                     const uint32_t framecount = first_frame + slot % count;
                     pt_f3 direction;
-                    if (get_bounce(mats, framecount, d, normal, __float_as_int(s0.w), multi, direction, seed)) {
+                    if (get_bounce(mats, nullptr, framecount, d, normal, __float_as_int(s0.w), multi, direction, seed)) {
                         cont = true;
                         rec.ox = o.x; rec.oy = o.y; rec.oz = o.z; rec.seed = seed;
                         rec.dx = direction.x; rec.dy = direction.y; rec.dz = direction.z; rec.slot = slot;
@@ -1452,7 +1477,7 @@ static int lds_resident_threads(const pt_context *ctx, int *levels_out, size_t *
 {
     const size_t lds_total = 160 * 1024;
     const int levels = 32 - __builtin_clz((unsigned)ctx->n | 1u);
-    const size_t nodes = (size_t)ctx->n * 48;
+    const size_t nodes = (size_t)ctx->n * 48 + PT_MAX_MATERIALS * 64;      // + materials and their quotients
     if (nodes + (size_t)levels * 4 * 256 > lds_total) return 0;
     size_t t = (lds_total - nodes) / ((size_t)levels * 4);
     t = t > 1024 ? 1024 : (t / 64) * 64;
@@ -1486,7 +1511,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
     size_t lds_bytes = 0;
     int threads = lds_resident_threads(ctx, &levels, &lds_bytes);
     if (const char *e = getenv("PTAMD_NO_LDS_TREE")) if (atoi(e)) threads = 0;
-    if (const char *e = getenv("PTAMD_LDS_THREADS")) { int t = atoi(e); if (t >= 64 && t <= threads) { threads = (t / 64) * 64; lds_bytes = (size_t)ctx->n * 48 + (size_t)levels * 4 * threads; } }
+    if (const char *e = getenv("PTAMD_LDS_THREADS")) { int t = atoi(e); if (t >= 64 && t <= threads) { threads = (t / 64) * 64; lds_bytes = (size_t)ctx->n * 48 + PT_MAX_MATERIALS * 64 + (size_t)levels * 4 * threads; } }
     static const bool no_order = getenv("PTAMD_NO_ORDER") && atoi(getenv("PTAMD_NO_ORDER"));
 
     bool wavefront = threads >= 256 && ctx->schedule == PT_SCHEDULE_WAVEFRONT;
