@@ -14,11 +14,10 @@
 // Execution shape.  Every path writes its radiance sample into a [pixel][frame]
 // staging buffer and k_accumulate folds the frames of a launch into the images
 // in frame order, so which lane traces which path never enters a result.
-//   k_trace      any tree (nodes in global memory): one lane per pixel, a wave
-//                covers an 8x8 tile, a lane runs its pixel's frames back to back.
-//   k_trace_lds  trees that fit in LDS: one persistent workgroup per CU, lanes
-//                take (pixel, frame chunk) items from a global queue, most
-//                expensive pixels first.
+//   k_trace_persistent  one persistent workgroup per CU, lanes take (pixel, frame
+//                chunk) items from a global queue, most expensive pixels first;
+//                the node records are held in LDS when the tree fits, else read
+//                from global memory.
 //   k_wf_*       the same paths bounce by bounce over queues (optional schedule).
 // All of them keep the current node in a register and only the pending right
 // children on a per-lane LDS stack.
@@ -310,15 +309,14 @@ __device__ __forceinline__ void lane_pixel(int &x, int &y)
 constexpr int MAX_ITR = 5;   // ray_tracing.hlsl:245-247
 
 // ---------------------------------------------------------------------------
-// ray_tracing.hlsl:348-420 for `count` consecutive frames of one pixel, as a
-// wave-level state machine.
+// ray_tracing.hlsl:348-420 as a wave-level state machine.
 //
 // A lane is either TRAVERSING (it owns a ray and a current node) or IDLE (its
-// ray is finished: it needs shading, a new ray, or the next frame's path).
-// Paths of a wave's 64 lanes have very different lengths, and a traversal step
-// is one of three different things (expand an internal node, test a triangle,
-// pop).  Run naively, each lane drags the whole wave through its own control
-// flow.  Instead the wave alternates between
+// ray is finished: it needs shading, a new ray, or the next path).  Paths of a
+// wave's 64 lanes have very different lengths, and a traversal step is one of
+// three different things (expand an internal node, test a triangle, pop).  Run
+// naively, each lane drags the whole wave through its own control flow.
+// Instead the wave alternates between
 //   * a refill phase, entered when at least REFILL_T lanes are idle (or nobody
 //     traverses): idle lanes shade their hit, continue or end their path, start
 //     the next frame's path, and set up the next ray;
@@ -329,226 +327,7 @@ constexpr int MAX_ITR = 5;   // ray_tracing.hlsl:245-247
 // Per lane the order of node visits, tests and random draws is exactly that of
 // the sequential loop, so results do not change.
 // ---------------------------------------------------------------------------
-constexpr int IDLE = (int)0x80000001;      // no ray in flight
 struct Tuning { int refill_t, leaf_t; };
-
-template <bool COUNT>
-__global__ __launch_bounds__(TRACE_THREADS) void k_trace(SceneView sc, int W, int H,
-                                                         const uint8_t *__restrict__ diffuse_tex,
-                                                         const float4 *__restrict__ normal_tex,
-                                                         const float4 *__restrict__ world_tex,
-                                                         uint32_t first_frame, uint32_t count,
-                                                         const uint32_t *__restrict__ seeds,
-                                                         float4 *__restrict__ samples, DevCounters *__restrict__ counters,
-                                                         Tuning tune)
-{
-    extern __shared__ __attribute__((aligned(16))) uint2 lds_stack[];
-    uint2 *stack = lds_stack + threadIdx.x;
-    constexpr int stride = TRACE_THREADS;
-    const int REFILL_T = tune.refill_t, LEAF_T = tune.leaf_t;
-
-    int x, y;
-    lane_pixel(x, y);
-    LaneCounters cnt;
-    const bool in_image = (x < W && y < H);
-    const size_t p = in_image ? (size_t)y * (size_t)W + (size_t)x : 0;
-    const float4 *mats = reinterpret_cast<const float4 *>(sc.cb->mats);
-
-    // per-pixel constants of the first bounce (ray_tracing.hlsl:349-367)
-    const uchar4 dif8 = reinterpret_cast<const uchar4 *>(diffuse_tex)[p];
-    const float4 nrm4 = normal_tex[p];
-    const float4 pos4 = world_tex[p];
-    const int matid0 = __float_as_int(nrm4.w) - 1;                  // asint(normal.w) - 1
-    const bool background = (matid0 < 0);
-    const pt_f3 hit_pos = pt_mk3(pos4.x, pos4.y, pos4.z);
-    pt_f3 multi0 = pt_mk3(dif8.x / 255.0f, dif8.y / 255.0f, dif8.z / 255.0f);
-    pt_f3 view0 = pt_mk3(0, 0, 0), normal0 = pt_mk3(0, 0, 0);
-    if (in_image && !background) {
-        const pt_f3 g_pos = pt_mk3(sc.cb->pos.v[0], sc.cb->pos.v[1], sc.cb->pos.v[2]);
-        if (mats[3 * matid0].y > 1) multi0 = pt_mk3(1, 1, 1);
-        view0 = pt_normalize3(pt_sub3(hit_pos, g_pos));
-        normal0 = pt_normalize3(pt_mk3(nrm4.x, nrm4.y, nrm4.z));
-    }
-    // ray_tracing.hlsl:410: uint(launchIndex.x + launchIndex.y * viewportDims.x), in float
-    const uint32_t pixel_id = (uint32_t)((float)(uint32_t)x + (float)(uint32_t)y * (float)W);
-    const float root_mn[3] = {sc.root[0], sc.root[1], sc.root[2]}, root_mx[3] = {sc.root[3], sc.root[4], sc.root[5]};
-
-    // the radiance sample of local frame fl (ray_tracing.hlsl:396-411: `multi` or black)
-    auto emit = [&](const pt_f3 &color, uint32_t fl) {
-        samples[p * count + fl] = make_float4(color.x, color.y, color.z, 1.0f);
-    };
-
-    // lane state
-    uint32_t f = 0;                       // next frame of this pixel
-    bool alive = in_image;                // frames left or a path in flight
-    bool path_active = false;             // a path of frame f is in flight
-    int cur = IDLE, sp = 0;
-    uint32_t seed = 0;
-    int itr = 1;
-    pt_f3 multi = pt_mk3(0, 0, 0);
-    Ray ray;
-    ray.o = hit_pos; ray.d = pt_mk3(0, 0, 1); ray.t_min = PT_EPSILON; ray.t_max = 10000;
-    pt_f3 inv = pt_mk3(1, 1, 1);
-    float current_t = 0;
-    bool intersected = false;
-    int hit_prim = 0;
-    float hit_bx = 0, hit_by = 0, hit_bz = 0;
-
-    if (alive && background) {
-        // ray_tracing.hlsl:361-362: black, but still accumulated every frame
-        for (uint32_t k = 0; k < count; k++) { cnt.paths++; emit(pt_mk3(0, 0, 0), k); }
-        alive = false;
-    }
-
-    for (;;) {
-        // ------------------------------------------------------------ refill
-        const bool need = alive && cur == IDLE;
-        const unsigned long long need_mask = ballot64(need);
-        const unsigned long long trav_mask = ballot64(alive && cur != IDLE);
-        if (need_mask == 0 && trav_mask == 0) break;
-        if (need_mask != 0 && (__popcll(need_mask) >= REFILL_T || trav_mask == 0)) {
-            if (need) {
-                bool have_ray = false;
-                do {
-                    pt_f3 direction;
-                    bool cont = false;                      // path continues with `direction`
-                    if (path_active) {
-                        // back from intersect() (ray_tracing.hlsl:372-395)
-                        const uint32_t framecount = first_frame + f;
-                        pt_f3 color = pt_mk3(0, 0, 0);
-                        if (intersected) {
-                            ray.o = pt_add3(ray.o, pt_scale3(ray.d, current_t));
-                            itr++;
-                            const float4 *shp = reinterpret_cast<const float4 *>(&sc.shade[hit_prim]);
-                            const float4 s0 = shp[0], s1 = shp[1], s2 = shp[2];
-                            const int matid = __float_as_int(s0.w);
-                            bool ended = false;
-                            if (itr > MAX_ITR) {
-                                const float pr = pt_max(pt_max(multi.x, multi.y), multi.z);
-                                if (pr > rand_next(seed)) multi = pt_scale3(multi, 1 / pr);
-                                else ended = true;
-                            }
-                            if (!ended && itr >= MAX_ITR * 3) ended = true;
-                            if (!ended) {
-                                const pt_f3 A = pt_mk3(s0.x, s0.y, s0.z), B = pt_mk3(s1.x, s1.y, s1.z), C = pt_mk3(s2.x, s2.y, s2.z);
-                                const pt_f3 new_normal = pt_add3(pt_add3(pt_scale3(A, hit_bz), pt_scale3(B, hit_bx)), pt_scale3(C, hit_by));
-                                if (get_bounce(mats, nullptr, framecount, ray.d, new_normal, matid, multi, direction, seed)) cont = true;
-                                else color = multi;
-                            }
-                        }
-                        if (!cont) {
-                            emit(color, f);
-                            path_active = false;
-                            f++;
-                        }
-                    } else if (f < count) {
-                        // new path of frame f (ray_tracing.hlsl:348-370, 410)
-                        const uint32_t framecount = first_frame + f;
-                        cnt.paths++;
-                        seed = rand_init(pixel_id, seeds[f]);
-                        multi = multi0;
-                        itr = 1;
-                        ray.o = hit_pos;
-                        if (get_bounce(mats, nullptr, framecount, view0, normal0, matid0, multi, direction, seed)) {
-                            cont = true;
-                            path_active = true;
-                        } else {
-                            emit(multi, f);
-                            f++;
-                        }
-                    } else {
-                        alive = false;
-                    }
-                    if (cont) {
-                        // start intersect() (ray_tracing.hlsl:191-214) with the root's own box test
-                        ray.d = direction;
-                        inv = pt_mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-                        current_t = ray.t_max;
-                        intersected = false;
-                        sp = 0;
-                        cnt.rays++;
-                        if (COUNT) { cnt.node_visits++; cnt.box_tests++; }
-                        float t_entry;
-                        if (slab(root_mn, root_mx, ray.o, inv, t_entry) && t_entry <= current_t) {
-                            cur = 0;
-                            have_ray = true;
-                        }
-                        // else: a miss; the loop handles it like any finished ray
-                    }
-                } while (alive && !have_ray);
-            }
-        }
-        // --------------------------------------------------------- traversal
-        for (;;) {
-            const bool trav = alive && cur != IDLE;
-            const unsigned long long tm = ballot64(trav);
-            if (tm == 0) break;
-            if (__popcll(ballot64(alive && cur == IDLE)) >= REFILL_T) break;
-            if (trav && cur >= 0) {
-                const float4 *w = reinterpret_cast<const float4 *>(&sc.wide[cur]);
-                const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-                const float lmn[3] = {w0.x, w0.y, w0.z}, lmx[3] = {w0.w, w1.x, w1.y};
-                const float rmn[3] = {w1.z, w1.w, w2.x}, rmx[3] = {w2.y, w2.z, w2.w};
-                const int left = __float_as_int(w3.x), right = __float_as_int(w3.y);
-                float tl, tr;
-                const bool hl = slab(lmn, lmx, ray.o, inv, tl) && tl <= current_t;
-                const bool hr = slab(rmn, rmx, ray.o, inv, tr) && tr <= current_t;
-                if (COUNT) { cnt.node_visits += 2; cnt.box_tests += 2; }
-                if (hl) {
-                    if (hr) { stack[sp * stride] = make_uint2((unsigned)right, __float_as_uint(tr)); sp++; }
-                    cur = left;
-                } else {
-                    cur = hr ? right : POP;
-                }
-            }
-            const bool at_leaf = trav && cur < 0 && cur != POP;
-            const unsigned long long leaf_mask = ballot64(at_leaf);
-            if (leaf_mask != 0 && (__popcll(leaf_mask) >= LEAF_T || ballot64(trav && cur >= 0) == 0)) {
-                if (at_leaf) {
-                    const int prim = ~cur;
-                    const float4 *tp = reinterpret_cast<const float4 *>(&sc.tri[prim]);
-                    const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
-                    if (COUNT) cnt.tri_tests++;
-                    // ray_tracing.hlsl:167-189
-                    const pt_f3 a = pt_mk3(t0.x, t0.y, t0.z), e_1 = pt_mk3(t1.x, t1.y, t1.z), e_2 = pt_mk3(t2.x, t2.y, t2.z);
-                    const pt_f3 q = pt_cross3(ray.d, e_2);
-                    const float a1 = pt_dot3(e_1, q);
-                    if (!(fabsf(a1) <= PT_EPSILON)) {
-                        const pt_f3 oa = pt_sub3(ray.o, a);
-                        const pt_f3 s = pt_mk3(oa.x / a1, oa.y / a1, oa.z / a1);
-                        const pt_f3 r = pt_cross3(s, e_1);
-                        const float t = pt_dot3(e_2, r);
-                        const float bx = pt_dot3(s, q);
-                        const float by = pt_dot3(r, ray.d);
-                        const float bz = 1 - bx - by;
-                        if (bx >= -PT_EPSILON && by >= -PT_EPSILON && bz >= -PT_EPSILON && t >= PT_EPSILON) {
-                            if (current_t > t && t > ray.t_min) {
-                                hit_bx = bx; hit_by = by; hit_bz = bz;
-                                current_t = t;
-                                hit_prim = prim;
-                                intersected = true;
-                            }
-                        }
-                    }
-                    cur = POP;
-                }
-            }
-            if (trav && cur == POP) {
-                // one pending child per iteration; entries whose entry distance no
-                // longer passes the distance test are dropped
-                if (sp == 0) {
-                    cur = IDLE;
-                } else {
-                    sp--;
-                    const uint2 e = stack[sp * stride];
-                    if (__uint_as_float(e.y) <= current_t) cur = (int)e.x;
-                }
-            }
-        }
-    }
-
-    flush_counters(cnt, counters, COUNT);
-}
 
 // ---------------------------------------------------------------------------
 // Path seeds of one launch: seed(pixel, frame) = rand_init(pixel id, g_random[0] of the frame)
@@ -570,13 +349,14 @@ __global__ __launch_bounds__(256) void k_path_seeds(int W, unsigned npix, uint32
 }
 
 // ---------------------------------------------------------------------------
-// The same state machine with the tree held in LDS, for scenes whose node
-// records fit (48 bytes per internal node: the two child boxes).
+// k_trace_persistent: that state machine as one persistent workgroup per CU.
 //
-// Why: every node visit is a per-lane random 64-byte gather.  Through the vector
-// L1 that is one tag lookup per lane per 16 bytes, and the L1 tag pipeline
-// (about one access per clock per CU) becomes the limit long before the VALU
-// does.  LDS serves sixteen 16-byte lane reads per clock.
+// LDSN = true, for scenes whose node records fit (48 bytes per internal node: the
+// two child boxes): the tree is held in LDS.  Every node visit is a per-lane
+// random gather; through the vector L1 that is one tag lookup per lane per 16
+// bytes, and the L1 tag pipeline (about one access per clock per CU) becomes the
+// limit long before the VALU does.  LDS serves sixteen 16-byte lane reads per
+// clock.  LDSN = false: the same records are read from global memory.
 //
 // Child ids are not stored.  The tree over keys 0..n is the binary trie of the
 // key indices, so a node is named by (first key s, level k): its left child is
@@ -601,8 +381,8 @@ __global__ __launch_bounds__(256) void k_path_seeds(int W, unsigned npix, uint32
 // loop control are the comparison masks themselves.
 constexpr int K_POP = -1, K_IDLE = -2, K_NOITEM = -3;
 
-template <bool COUNT>
-__global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect *__restrict__ tri_sorted, int levels,
+template <bool COUNT, bool LDSN>
+__global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const TriIsect *__restrict__ tri_sorted, int levels,
                                                     int W, int H,
                                                     const uint8_t *__restrict__ diffuse_tex,
                                                     const float4 *__restrict__ normal_tex,
@@ -614,17 +394,19 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
                                                     const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
                                                     uint32_t chunk, Tuning tune)
 {
-    // LDS: node records (3 float4 each), the 16 materials (3 float4 each), their quotient records
-    // (1 float4 each), then the per-lane stacks
+    // LDS: node records (3 float4 each; LDSN only), the 16 materials (3 float4 each), their quotient
+    // records (1 float4 each), then the per-lane stacks
     extern __shared__ __attribute__((aligned(16))) float4 lds_nodes[];
     const int n = sc.n;
     const int nthreads = blockDim.x;
-    float4 *lds_mats = lds_nodes + 3 * n;
+    float4 *lds_mats = lds_nodes + (LDSN ? 3 * n : 0);
     float4 *lds_matq = lds_mats + 3 * PT_MAX_MATERIALS;
     float *stack = reinterpret_cast<float *>(lds_matq + PT_MAX_MATERIALS) + threadIdx.x;   // level L at stack[(L-1) * nthreads]
-    for (int i = threadIdx.x; i < 3 * n; i += nthreads) {
-        const int node = i / 3, part = i - 3 * node;
-        lds_nodes[i] = reinterpret_cast<const float4 *>(&sc.wide[node])[part];
+    if (LDSN) {
+        for (int i = threadIdx.x; i < 3 * n; i += nthreads) {
+            const int node = i / 3, part = i - 3 * node;
+            lds_nodes[i] = reinterpret_cast<const float4 *>(&sc.wide[node])[part];
+        }
     }
     if (threadIdx.x < 3 * PT_MAX_MATERIALS)
         lds_mats[threadIdx.x] = reinterpret_cast<const float4 *>(sc.cb->mats)[threadIdx.x];
@@ -833,7 +615,8 @@ __global__ __launch_bounds__(1024) void k_trace_lds(SceneView sc, const TriIsect
             }
             iterations++;
             if (cur_k >= 1) {                       // only traversing lanes have cur_k >= K_POP
-                const float4 *w = lds_nodes + __umul24((unsigned)cur_id, 3u);   // 24-bit multiply: full rate
+                const float4 *w = LDSN ? lds_nodes + __umul24((unsigned)cur_id, 3u)     // 24-bit multiply: full rate
+                                       : reinterpret_cast<const float4 *>(sc.wide + cur_id);
                 const float4 w0 = w[0], w1 = w[1], w2 = w[2];
                 const float lmn[3] = {w0.x, w0.y, w0.z}, lmx[3] = {w0.w, w1.x, w1.y};
                 const float rmn[3] = {w1.z, w1.w, w2.x}, rmx[3] = {w2.y, w2.z, w2.w};
@@ -1511,11 +1294,17 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
     size_t lds_bytes = 0;
     int threads = lds_resident_threads(ctx, &levels, &lds_bytes);
     if (const char *e = getenv("PTAMD_NO_LDS_TREE")) if (atoi(e)) threads = 0;
-    if (const char *e = getenv("PTAMD_LDS_THREADS")) { int t = atoi(e); if (t >= 64 && t <= threads) { threads = (t / 64) * 64; lds_bytes = (size_t)ctx->n * 48 + PT_MAX_MATERIALS * 64 + (size_t)levels * 4 * threads; } }
+    const bool lds_nodes = threads >= 256;          // else: node records stay in global memory
+    if (!lds_nodes) {
+        // LDS holds the materials and one float per tree level and lane
+        levels = 32 - __builtin_clz((unsigned)ctx->n | 1u);
+        threads = 1024;
+        lds_bytes = PT_MAX_MATERIALS * 64 + (size_t)levels * 4 * threads;
+    }
     static const bool no_order = getenv("PTAMD_NO_ORDER") && atoi(getenv("PTAMD_NO_ORDER"));
 
-    bool wavefront = threads >= 256 && ctx->schedule == PT_SCHEDULE_WAVEFRONT;
-    if (const char *e = getenv("PTAMD_MEGAKERNEL")) wavefront = threads >= 256 && !atoi(e);   // A/B runs
+    bool wavefront = lds_nodes && ctx->schedule == PT_SCHEDULE_WAVEFRONT;
+    if (const char *e = getenv("PTAMD_MEGAKERNEL")) wavefront = lds_nodes && !atoi(e);   // A/B runs
     const uint32_t per_launch = frames_per_launch(ctx, count, wavefront);
     if (ctx->samples_frames < per_launch) {
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1592,7 +1381,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
                 }
                 fprintf(stderr, "\n");
             }
-        } else if (threads >= 256) {
+        } else {
             // frames per work item: about 16 items per lane, so that the launch ends on short
             // items, in equal parts of the launch's frames
             const unsigned long long lanes = (unsigned long long)ctx->num_cus * threads;
@@ -1609,16 +1398,17 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
             hipLaunchKernelGGL(k_path_seeds, dim3((unsigned)ctx->num_cus * 16u), dim3(256), 0, ctx->stream, ctx->W, (unsigned)npix, cnt,
                                seeds, ctx->d_samples);
-#define PT_LAUNCH_LDS(C) do { \
-            PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_lds<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-            hipLaunchKernelGGL((k_trace_lds<C>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
+#define PT_LAUNCH(C, L) do { \
+            PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_persistent<C, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+            hipLaunchKernelGGL((k_trace_persistent<C, L>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
                 ctx->W, ctx->H, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, seeds, \
                 ctx->d_samples, ctx->d_counters, ctx->d_work, \
                 ctx->order_valid ? ctx->d_ovals[0] : (const uint32_t *)nullptr, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, \
                 (uint32_t)chunk, tune); } while (0)
             if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream));
-            if (ctx->detailed) PT_LAUNCH_LDS(true); else PT_LAUNCH_LDS(false);
-#undef PT_LAUNCH_LDS
+            if (lds_nodes) { if (ctx->detailed) PT_LAUNCH(true, true); else PT_LAUNCH(false, true); }
+            else           { if (ctx->detailed) PT_LAUNCH(true, false); else PT_LAUNCH(false, false); }
+#undef PT_LAUNCH
             if (ev_end) PT_HIP(ctx, hipEventRecord(ev_end, ctx->stream));
             PT_HIP(ctx, hipGetLastError());
             // queue order of the next launch from the decaying per-pixel iteration counts (about
@@ -1629,16 +1419,6 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
                 while ((top >> bits) != 0) bits++;
                 if (int rc = ptk_order_pixels(ctx, bits > 16 ? bits - 16 : 0)) return rc;
             }
-        } else {
-            dim3 grid((ctx->W + 15) / 16, (ctx->H + 15) / 16), block(TRACE_THREADS);
-            const size_t lds = stack_bytes(ctx);
-#define PT_LAUNCH_TRACE(C) hipLaunchKernelGGL((k_trace<C>), grid, block, lds, ctx->stream, sv, ctx->W, ctx->H, \
-                ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, seeds, ctx->d_samples, ctx->d_counters, tune)
-            if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream));
-            if (ctx->detailed) PT_LAUNCH_TRACE(true); else PT_LAUNCH_TRACE(false);
-#undef PT_LAUNCH_TRACE
-            if (ev_end) PT_HIP(ctx, hipEventRecord(ev_end, ctx->stream));
-            PT_HIP(ctx, hipGetLastError());
         }
         const dim3 agrid((unsigned)((npix + 255) / 256));
         if (lin) hipLaunchKernelGGL(k_accumulate<true>, agrid, dim3(256), 0, ctx->stream, ctx->d_samples, npix, first, cnt,
