@@ -238,7 +238,7 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "r01_trace_pmc.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("k_trace_lds", {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(pmc)).get("k_trace_persistent", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -266,7 +266,7 @@ def main():
                           "bytes_per_ray": bytes_per_ray},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_trace_lds", "launch_ms_avg": kern_avg_ms,
+                         "kernel": "k_trace_persistent", "launch_ms_avg": kern_avg_ms,
                          "note": "algorithmic bytes (36 B per node visit + 36 B per triangle test) over kernel time; "
                                  "the node records live in LDS and the triangles in L1/L2, so these bytes never "
                                  "reach HBM (see traffic): the kernel is VALU-issue bound, a fraction above 1 "

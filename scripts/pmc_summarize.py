@@ -8,7 +8,7 @@ for f in glob.glob(os.path.join(src, "*", "**", "*counter_collection.csv"), recu
         name = r["Kernel_Name"]
         m = re.search(r"(k_\w+)", name)
         k = m.group(1) if m else name.replace("void ", "").split("(")[0].strip()
-        if k in ("k_trace_lds", "k_trace", "k_wf_extend") and (k + "<true") in name:
+        if k in ("k_trace_persistent", "k_wf_extend") and (k + "<true") in name:
             k += "<detailed>"
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[k][r["Counter_Name"]] += 1
 res = {}
