@@ -155,9 +155,12 @@ int pt_download_display(pt_context *ctx, uint8_t *rgba8);
 int pt_output_device_ptr(pt_context *ctx, void **dev_rgba32f, void **dev_rgba8);
 
 /* ---- options & counters --------------------------------------------------------- */
-/* traversal stack entries per path: 15 = the reference (paths silently drop
- * subtrees beyond it, ray_tracing.hlsl:235-238); larger values are NON-PARITY
- * for trees deeper than 13 levels.  Allowed: 15 or 32 or 64. */
+/* traversal stack depth.  The reference keeps 15 entries per path and silently drops subtrees
+ * beyond them (ray_tracing.hlsl:235-238), which happens for trees deeper than 13 levels
+ * (n > 16383).  This library never drops (it keeps one pending child per tree level), so for
+ * such trees its images differ from the reference's: 15 makes the trace calls refuse those
+ * trees, 32 states the opt-in to the non-dropping result (NON-PARITY for deep trees), 0
+ * (default) traces any tree without asking.  Allowed: 0, 15, 32. */
 int pt_set_stack_size(pt_context *ctx, int entries);
 
 /* how pt_trace / pt_trace_frames schedule the paths of a launch on scenes whose tree fits
