@@ -234,35 +234,35 @@ __device__ __forceinline__ bool get_bounce(const float4 *mats, const float4 *mat
         return true;
     }
     const float4 mq = matq ? matq[id] : material_quotients(m0, m1, m2);
+    // Phong lobe around the mirror direction (ray_tracing.hlsl:303-321) or cosine lobe around the
+    // normal (:322-341).  Both build a frame (u, v, w) and combine it with cos / sin of r1; the
+    // branches only choose the operands, the shared tail evaluates the same expressions once for
+    // whichever lanes took either branch.
+    pt_f3 w, u_raw;
+    float r1, r2s, height;
     if (ns > 1 && rand_mat < mq.y) {
-        direction = pt_reflect3(view_dir, normal);
-        const float r1 = 2 * PT_MY_PI * ((framecount & 1) / 2.0f + rand_next(seed) / 2);
-        const float height = pt_powf((((framecount >> 1) & 3) / 4.0f + rand_next(seed) / 4), mq.x);
-        const float r2s = sqrtf(1 - height * height);
-        const pt_f3 w = direction;
-        const pt_f3 u = pt_normalize3(pt_cross3(w, view_dir));
-        const pt_f3 v = pt_cross3(w, u);
-        const pt_f3 d = pt_add3(pt_add3(pt_scale3(pt_scale3(u, pt_cosf(r1)), r2s),
-                                        pt_scale3(pt_scale3(v, pt_sinf(r1)), r2s)),
-                                pt_scale3(w, height));
-        direction = pt_normalize3(d);
+        w = pt_reflect3(view_dir, normal);
+        r1 = 2 * PT_MY_PI * ((framecount & 1) / 2.0f + rand_next(seed) / 2);
+        height = pt_powf((((framecount >> 1) & 3) / 4.0f + rand_next(seed) / 4), mq.x);
+        r2s = sqrtf(1 - height * height);
+        u_raw = pt_cross3(w, view_dir);
         multi = pt_mul3(multi, pt_mk3(m2.x, m2.y, m2.z));
     } else {
         multi = pt_mul3(multi, pt_mk3(m1.x, m1.y, m1.z));
-        const float r1 = 2 * PT_MY_PI * (((framecount >> 1) & 3) / 4.0f + rand_next(seed) / 4.0f);
+        r1 = 2 * PT_MY_PI * (((framecount >> 1) & 3) / 4.0f + rand_next(seed) / 4.0f);
         const float r2 = (((framecount >> 3) & 3) / 4.0f + rand_next(seed) / 4.0f);
-        const float r2s = sqrtf(r2);
-        const pt_f3 w = normal;
-        pt_f3 u;
-        if (fabsf(w.x) > 0.1f) u = pt_cross3(w, pt_mk3(0, 1, 0));
-        else u = pt_cross3(w, pt_mk3(1, 0, 0));
-        u = pt_normalize3(u);
-        const pt_f3 v = pt_cross3(w, u);
-        const pt_f3 d = pt_add3(pt_add3(pt_scale3(pt_scale3(u, pt_cosf(r1)), r2s),
-                                        pt_scale3(pt_scale3(v, pt_sinf(r1)), r2s)),
-                                pt_scale3(w, sqrtf(1 - r2)));
-        direction = pt_normalize3(d);
+        r2s = sqrtf(r2);
+        w = normal;
+        const bool y_axis = fabsf(w.x) > 0.1f;
+        u_raw = pt_cross3(w, pt_mk3(y_axis ? 0.0f : 1.0f, y_axis ? 1.0f : 0.0f, 0.0f));
+        height = sqrtf(1 - r2);
     }
+    const pt_f3 u = pt_normalize3(u_raw);
+    const pt_f3 v = pt_cross3(w, u);
+    const pt_f3 d = pt_add3(pt_add3(pt_scale3(pt_scale3(u, pt_cosf(r1)), r2s),
+                                    pt_scale3(pt_scale3(v, pt_sinf(r1)), r2s)),
+                            pt_scale3(w, height));
+    direction = pt_normalize3(d);
     return true;
 }
 
