@@ -211,13 +211,12 @@ __device__ __forceinline__ bool get_bounce(const float4 *mats, const float4 *mat
             direction = pt_reflect3(view_dir, normal);
             return true;
         }
-        if (cosv < 0) {
-            const float k = cosv * nnt + sqrtf(cos2t);
-            direction = pt_normalize3(pt_sub3(pt_scale3(view_dir, nnt), pt_scale3(normal, k)));
-        } else {
-            const float k = -cosv * nnt + sqrtf(cos2t);
-            direction = pt_normalize3(pt_add3(pt_scale3(view_dir, nnt), pt_scale3(normal, k)));
-        }
+        // view*nnt - normal*k (entering) or view*nnt + normal*k (leaving), ray_tracing.hlsl:272-281:
+        // a - b is a + (-b) bit for bit, so one normalize serves both
+        const float k = (cosv < 0 ? cosv : -cosv) * nnt + sqrtf(cos2t);
+        pt_f3 nk = pt_scale3(normal, k);
+        if (cosv < 0) nk = pt_mk3(-nk.x, -nk.y, -nk.z);
+        direction = pt_normalize3(pt_add3(pt_scale3(view_dir, nnt), nk));
         const float R0 = mq.w;               // (nt - nc)^2 / (nt + nc)^2
         const float c = 1 - ddn;
         const float Re = R0 + (1 - R0) * c * c * c * c * c;
