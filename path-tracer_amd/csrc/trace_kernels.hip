@@ -1061,32 +1061,56 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
 // Folds the samples of `count` frames (layout [pixel][frame]) into the images, frame by frame
 // in order.  LITERAL: ray_tracing.hlsl:412-419 on `output` / `old` plus the UNORM8 copy;
 // LINEAR: running float sum, alpha counts samples.
+// A lane owns one pixel (the recurrence is sequential in the frame index), but a pixel's frames
+// are 16 bytes apart while neighbouring pixels are `count`*16 bytes apart, so the wave loads
+// tiles of 64 pixels x 8 frames with 8 lanes per pixel (128 contiguous bytes each) and hands
+// them to the owning lanes through LDS.
+constexpr int ACC_FRAMES = 8;
+
 template <bool LINEAR>
 __global__ __launch_bounds__(256) void k_accumulate(const float4 *__restrict__ samples, size_t npix,
                                                     uint32_t first_frame, uint32_t count,
                                                     float4 *__restrict__ output, uint8_t *__restrict__ display,
                                                     float4 *__restrict__ linear)
 {
-    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= npix) return;
-    float4 acc = LINEAR ? linear[p] : output[p];
+    __shared__ float4 tile[4][64][ACC_FRAMES + 1];        // +1: lanes of a wave land in different banks
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t p0 = (size_t)blockIdx.x * 256 + (size_t)wave * 64;       // the wave's first pixel
+    const size_t p = p0 + lane;
+    const bool owner = p < npix;
+    float4 acc = make_float4(0, 0, 0, 0);
+    if (owner) acc = LINEAR ? linear[p] : output[p];
     const float inv_gamma = 1 / 2.2f;
-    for (uint32_t k = 0; k < count; k++) {
-        const float4 c = samples[p * count + k];
-        if (LINEAR) {
-            acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += 1.0f;
-        } else {
-            const uint32_t framecount = first_frame + k;
-            const float this_color[4] = {c.x, c.y, c.z, 1.0f};
-            const float old_factor = 1.0f * (float)framecount / (float)(framecount + 1);
-            const float new_factor = 1.0f / (float)(framecount + 1);
-            float o[4] = {acc.x, acc.y, acc.z, acc.w};
+    for (uint32_t k0 = 0; k0 < count; k0 += ACC_FRAMES) {
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                o[j] = pt_powf(pt_powf(o[j], 2.2f) * old_factor + this_color[j] * new_factor, inv_gamma);
-            acc = make_float4(o[0], o[1], o[2], o[3]);
+        for (int j = 0; j < 8; j++) {
+            const int pl = (lane >> 3) + 8 * j;                           // pixel within the wave's 64
+            const uint32_t k = k0 + (lane & 7);
+            if (p0 + pl < npix && k < count) tile[wave][pl][lane & 7] = samples[(p0 + pl) * count + k];
         }
+        __builtin_amdgcn_wave_barrier();                                   // the tile is private to the wave
+        const uint32_t kn = min((uint32_t)ACC_FRAMES, count - k0);
+        if (owner) {
+            for (uint32_t kk = 0; kk < kn; kk++) {
+                const float4 c = tile[wave][lane][kk];
+                if (LINEAR) {
+                    acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += 1.0f;
+                } else {
+                    const uint32_t framecount = first_frame + k0 + kk;
+                    const float this_color[4] = {c.x, c.y, c.z, 1.0f};
+                    const float old_factor = 1.0f * (float)framecount / (float)(framecount + 1);
+                    const float new_factor = 1.0f / (float)(framecount + 1);
+                    float o[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        o[j] = pt_powf(pt_powf(o[j], 2.2f) * old_factor + this_color[j] * new_factor, inv_gamma);
+                    acc = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
+    if (!owner) return;
     if (LINEAR) {
         linear[p] = acc;
     } else {
