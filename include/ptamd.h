@@ -79,7 +79,8 @@ typedef enum pt_build_stage {
     PT_STAGE_SORT,         /* radix sort (all passes)         */
     PT_STAGE_TOPOLOGY,     /* binary radix tree links         */
     PT_STAGE_REFIT,        /* leaf init + bottom-up AABBs     */
-    PT_STAGE_PACK,         /* triangle records for traversal  */
+    PT_STAGE_PACK,         /* triangle records in leaf order for the trace kernels (the per-triangle
+                              records are written by the bounds stage) */
     PT_STAGE_COUNT
 } pt_build_stage;
 /* device-side durations (ms, HIP events) of the last pt_build; total = sum.

@@ -37,7 +37,6 @@ static void free_build(pt_context *ctx)
     dev_free(ctx->d_tree);
     dev_free(ctx->d_wide);
     dev_free(ctx->d_chunk);
-    dev_free(ctx->d_tri);
     dev_free(ctx->d_shade);
     dev_free(ctx->d_tri_sorted);
     ctx->capacity = 0;
@@ -209,7 +208,6 @@ static int ensure_build_buffers(pt_context *ctx)
     if (!rc) rc = dev_alloc(ctx, &ctx->d_block_hist, 256 * nblocks);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_wide, (size_t)n);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_chunk, nchunks + (nchunks + 2047) / 2048 + 1);
-    if (!rc) rc = dev_alloc(ctx, &ctx->d_tri, (size_t)n);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_shade, (size_t)n);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_tri_sorted, (size_t)n + 1);
     if (rc) { free_build(ctx); return rc; }
@@ -227,8 +225,6 @@ int pt_build(pt_context *ctx, unsigned flags)
     ctx->built = false;
     ctx->tree_exported = false;
     if (int rc = ptk_build(ctx, flags)) return rc;
-    if (int rc = ptk_root_box(ctx)) return rc;
-    if (int rc = ptk_sort_tris(ctx)) return rc;
     ctx->build_flags = flags;
     ctx->built = true;
     return PT_OK;

@@ -48,7 +48,7 @@ constexpr int PRIM_DW = 20;   // dwords per PrimitiveRender
 
 __global__ __launch_bounds__(256) void k_bounds(const uint4 *__restrict__ prims16, int n,
                                                 BoxRec *__restrict__ boxes, float *__restrict__ partial,
-                                                TriIsect *__restrict__ tri, TriShade *__restrict__ shade)
+                                                TriShade *__restrict__ shade)
 {
     __shared__ uint4 stage[256 * PRIM_DW / 4];      // 20480 B
     __shared__ float red[6][4];
@@ -77,13 +77,9 @@ __global__ __launch_bounds__(256) void k_bounds(const uint4 *__restrict__ prims1
         float4 *dst = reinterpret_cast<float4 *>(&boxes[first + t]);
         dst[0] = make_float4(b.mn[0], b.mn[1], b.mn[2], 0.0f);
         dst[1] = make_float4(b.mx[0], b.mx[1], b.mx[2], __int_as_float(b.index));
-        // the triangle records of the trace kernels (vertex + two edges; the three normals), while
-        // the primitive is at hand: a pass of its own would read the 80-byte records again
+        // the shading record of the trace kernels (the three normals and the material), while the
+        // primitive is at hand: a pass of its own would read the 80-byte records again
         const int matid = reinterpret_cast<const int *>(p)[18];
-        float4 *ti = reinterpret_cast<float4 *>(&tri[first + t]);
-        ti[0] = make_float4(p[0], p[1], p[2], __int_as_float(matid));
-        ti[1] = make_float4(p[6] - p[0], p[7] - p[1], p[8] - p[2], 0.0f);
-        ti[2] = make_float4(p[12] - p[0], p[13] - p[1], p[14] - p[2], 0.0f);
         float4 *ts = reinterpret_cast<float4 *>(&shade[first + t]);
         ts[0] = make_float4(p[3], p[4], p[5], __int_as_float(matid));
         ts[1] = make_float4(p[9], p[10], p[11], 0.0f);
@@ -399,23 +395,20 @@ __global__ __launch_bounds__(PT_REFIT_CHUNK) void k_refit_low(const uint32_t *__
                                                    int n, WideNode *__restrict__ wide, ChunkBox *__restrict__ chunk)
 {
     __shared__ float sb[6][PT_REFIT_CHUNK];          // 24 KB: min.xyz, max.xyz per key slot
-    __shared__ int sprim[PT_REFIT_CHUNK];            //  4 KB
     const int t = threadIdx.x;
     const long long base = (long long)blockIdx.x * PT_REFIT_CHUNK;
     {   // one key per lane: every gather of the chunk is in flight at once
         const int j = t;
         long long key = base + j;
         float b[6] = {0, 0, 0, 0, 0, 0};
-        int p = 0;
         if (key < n) {
-            p = (int)perm[key];
+            const int p = (int)perm[key];
             const float4 *src = reinterpret_cast<const float4 *>(&boxes[p]);
             float4 lo = src[0], hi = src[1];
             b[0] = lo.x; b[1] = lo.y; b[2] = lo.z; b[3] = hi.x; b[4] = hi.y; b[5] = hi.z;
         }
 #pragma unroll
         for (int c = 0; c < 6; c++) sb[c][j] = b[c];
-        sprim[j] = p;
     }
     __syncthreads();
     for (int k = 1; k <= PT_REFIT_CHUNK_LOG2; k++) {
@@ -434,8 +427,9 @@ __global__ __launch_bounds__(PT_REFIT_CHUNK) void k_refit_low(const uint32_t *__
                 const int id = node_id(b, k, n);
                 const long long gamma = s + half - 1;
                 const long long e = min(s + (1ll << k) - 1, (long long)n);
-                const int left = (k == 1) ? ~sprim[ls] : (int)gamma;
-                const int right = (gamma + 1 == e) ? ~sprim[rs] : (int)(gamma + 1);
+                // a leaf child is named ~key (its position in the sorted order)
+                const int left = (k == 1) ? ~(int)s : (int)gamma;
+                const int right = (gamma + 1 == e) ? ~(int)(gamma + 1) : (int)(gamma + 1);
                 write_wide(&wide[id], L, R, left, right);
 #pragma unroll
                 for (int c = 0; c < 6; c++) sb[c][ls] = U[c];
@@ -487,7 +481,7 @@ __global__ __launch_bounds__(1024) void k_refit_upper(int base, int top, int n, 
                 const long long gamma = s + half - 1;
                 const long long e = min(s + (1ll << k) - 1, (long long)n);
                 // above chunk level a single-key right range can only be key n itself
-                const int right = (gamma + 1 == e) ? ~0 : (int)(gamma + 1);
+                const int right = (gamma + 1 == e) ? ~(int)(gamma + 1) : (int)(gamma + 1);
                 write_wide(&wide[node_id(s >> k, k, n)], L, R, (int)gamma, right);
 #pragma unroll
                 for (int c = 0; c < 6; c++) sb[c][ls] = U[c];
@@ -626,7 +620,7 @@ int ptk_build(pt_context *ctx, unsigned flags)
     const uint4 *prims16 = reinterpret_cast<const uint4 *>(ctx->d_prims);
 
     PT_HIP(ctx, hipEventRecord(ctx->ev[0], st));
-    hipLaunchKernelGGL(k_bounds, dim3(grid_n), dim3(256), 0, st, prims16, n, ctx->d_boxes, ctx->d_bbox_partial, ctx->d_tri, ctx->d_shade);
+    hipLaunchKernelGGL(k_bounds, dim3(grid_n), dim3(256), 0, st, prims16, n, ctx->d_boxes, ctx->d_bbox_partial, ctx->d_shade);
     hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(1024), 0, st, ctx->d_bbox_partial, grid_n, ctx->d_bbox_enc);
     PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_BOUNDS + 1], st));
 
@@ -677,9 +671,12 @@ int ptk_build(pt_context *ctx, unsigned flags)
     }
     PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_REFIT + 1], st));
 
-    // the triangle records were written by the bounds kernel: nothing runs in this stage
-    PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_PACK + 1], st));
+    // records for the trace kernels: the per-triangle ones were written by the bounds kernel; what is
+    // left is the root's own box and the triangle records in leaf order
     PT_HIP(ctx, hipGetLastError());
+    if (int rc = ptk_root_box(ctx)) return rc;
+    if (int rc = ptk_sort_tris(ctx)) return rc;
+    PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_PACK + 1], st));
     return PT_OK;
 }
 

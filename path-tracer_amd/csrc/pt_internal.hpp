@@ -98,7 +98,6 @@ struct pt_context {
     WideNode *d_wide = nullptr;       // n
     ChunkBox *d_chunk = nullptr;      // ceil((n+1)/1024)
     float *d_root = nullptr;          // the root's own box (6 floats)
-    TriIsect *d_tri = nullptr;        // n
     TriShade *d_shade = nullptr;      // n
     TriIsect *d_tri_sorted = nullptr; // n+1, leaf-key order, primitive id in the spare word
     unsigned *d_work = nullptr;       // pixel queue head of the persistent trace kernel

@@ -135,9 +135,10 @@ __device__ __forceinline__ bool traverse(const SceneView &sc, const Ray &ray, ui
                 cur = hr ? right : POP;
             }
         } else if (cur != POP) {
-            const int prim = ~cur;
-            const float4 *tp = reinterpret_cast<const float4 *>(&sc.tri[prim]);
+            // leaves are ~key; the record in leaf order carries the primitive id in its spare word
+            const float4 *tp = reinterpret_cast<const float4 *>(&sc.tri[~cur]);
             const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+            const int prim = __float_as_int(t0.w);
             if (COUNT) cnt.tri_tests++;
             // ray_tracing.hlsl:167-189
             const pt_f3 a = pt_mk3(t0.x, t0.y, t0.z), e_1 = pt_mk3(t1.x, t1.y, t1.z), e_2 = pt_mk3(t2.x, t2.y, t2.z);
@@ -1121,21 +1122,22 @@ __global__ __launch_bounds__(256) void k_accumulate(const float4 *__restrict__ s
     }
 }
 
-// triangle records in sorted (leaf key) order, primitive id in the spare word;
-// entry n belongs to the out-of-range leaf (primitive 0)
-__global__ __launch_bounds__(256) void k_sort_tris(const TriIsect *__restrict__ tri, const uint32_t *__restrict__ perm, int n,
-                                                   TriIsect *__restrict__ out)
+// triangle records of the traversal ({a, e1 = b - a, e2 = c - a}) in leaf-key order, straight from the
+// primitives, the primitive id in the spare word; entry n belongs to the out-of-range leaf (primitive 0)
+__global__ __launch_bounds__(256) void k_sort_tris(const pt_PrimitiveRender *__restrict__ prims, const uint32_t *__restrict__ perm,
+                                                   int n, TriIsect *__restrict__ out)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j > n) return;
     const int p = (j < n) ? (int)perm[j] : 0;
-    const float4 *src = reinterpret_cast<const float4 *>(&tri[p]);
+    // xyzn x 3 = 20 floats: positions at floats 0..2, 6..8, 12..14; four 16-byte loads cover them
+    const float4 *src = reinterpret_cast<const float4 *>(&prims[p]);
+    const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+    const float a[3] = {v0.x, v0.y, v0.z};
     float4 *dst = reinterpret_cast<float4 *>(&out[j]);
-    float4 r0 = src[0];
-    r0.w = __int_as_float(p);
-    dst[0] = r0;
-    dst[1] = src[1];
-    dst[2] = src[2];
+    dst[0] = make_float4(a[0], a[1], a[2], __int_as_float(p));
+    dst[1] = make_float4(v1.z - a[0], v1.w - a[1], v2.x - a[2], 0.0f);
+    dst[2] = make_float4(v3.x - a[0], v3.y - a[1], v3.z - a[2], 0.0f);
 }
 
 // out = pow(sum.rgb / sum.a, 1/2.2), alpha 1
@@ -1246,7 +1248,7 @@ __global__ void k_root_box(const WideNode *__restrict__ wide, float *__restrict_
 static int make_view(pt_context *ctx, SceneView &sv)
 {
     sv.wide = ctx->d_wide;
-    sv.tri = ctx->d_tri;
+    sv.tri = ctx->d_tri_sorted;
     sv.shade = ctx->d_shade;
     sv.cb = ctx->d_cb;
     sv.root = ctx->d_root;
@@ -1272,7 +1274,7 @@ static size_t stack_bytes(const pt_context *ctx)
 int ptk_sort_tris(pt_context *ctx)
 {
     hipLaunchKernelGGL(k_sort_tris, dim3((ctx->n + 1 + 255) / 256), dim3(256), 0, ctx->stream,
-                       ctx->d_tri, ctx->d_vals[ctx->sorted_buf], ctx->n, ctx->d_tri_sorted);
+                       ctx->d_prims, ctx->d_vals[ctx->sorted_buf], ctx->n, ctx->d_tri_sorted);
     PT_HIP(ctx, hipGetLastError());
     return PT_OK;
 }
