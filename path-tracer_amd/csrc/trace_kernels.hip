@@ -602,42 +602,68 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
         }
         const long long t_trav = COUNT ? (long long)__builtin_readcyclecounter() : 0;
         // --------------------------------------------------------- traversal
-        for (;;) {
-            const bool trav = cur_k >= K_POP;
-            if (ballot64(trav) == 0) break;
-            if (__popcll(need_vote()) >= REFILL_T) break;
-            if (COUNT) {
-                sched[0]++;
-                sched[1] += __popcll(ballot64(cur_k >= 1));
-                sched[4] += __popcll(ballot64(cur_k == 0));                     // waiting at a leaf
-                sched[6] += __popcll(ballot64(cur_k == K_IDLE));                       // waiting for a refill
-                sched[7] += __popcll(ballot64(cur_k == K_NOITEM));                     // no item (queue empty)
-            }
-            iterations++;
-            if (cur_k >= 1) {                       // only traversing lanes have cur_k >= K_POP
-                const float4 *w = LDSN ? lds_nodes + __umul24((unsigned)cur_id, 3u)     // 24-bit multiply: full rate
-                                       : reinterpret_cast<const float4 *>(sc.wide + cur_id);
-                const float4 w0 = w[0], w1 = w[1], w2 = w[2];
-                const float lmn[3] = {w0.x, w0.y, w0.z}, lmx[3] = {w0.w, w1.x, w1.y};
-                const float rmn[3] = {w1.z, w1.w, w2.x}, rmx[3] = {w2.y, w2.z, w2.w};
-                float tl, tr;
-                const bool hl = slab(lmn, lmx, ray.o, inv, tl) && tl <= current_t;
-                const bool hr = slab(rmn, rmx, ray.o, inv, tr) && tr <= current_t;
-                if (COUNT) { cnt.node_visits += 2; cnt.box_tests += 2; }
-                const int k = cur_k, half = 1 << (k - 1);
-                if (hl) {
-                    if (hr) { stack[__umul24((unsigned)(k - 1), (unsigned)nthreads)] = tr; pending |= 1u << k; }
-                    cur_k = k - 1;
-                    cur_id = cur_s + half - 1;
-                } else if (hr) {
-                    const int sr = cur_s + half, e = min(cur_s + 2 * half - 1, n);
-                    cur_k = 32 - __clz(sr ^ e);
-                    cur_s = sr;
-                    cur_id = sr;
-                } else {
-                    cur_k = K_POP;
+        // One loop pass = two node expansions, each followed by a pop attempt, with the loop control
+        // and the triangle-test decision once per pass (they cost as much as a fifth of an expansion).
+        auto expand = [&]() {
+                if (COUNT) {
+                    sched[0]++;
+                    sched[1] += __popcll(ballot64(cur_k >= 1));
+                    sched[4] += __popcll(ballot64(cur_k == 0));                     // waiting at a leaf
+                    sched[6] += __popcll(ballot64(cur_k == K_IDLE));                       // waiting for a refill
+                    sched[7] += __popcll(ballot64(cur_k == K_NOITEM));                     // no item (queue empty)
                 }
-            }
+                iterations++;
+                if (cur_k >= 1) {                       // only traversing lanes have cur_k >= K_POP
+                    const float4 *w = LDSN ? lds_nodes + __umul24((unsigned)cur_id, 3u)     // 24-bit multiply: full rate
+                                           : reinterpret_cast<const float4 *>(sc.wide + cur_id);
+                    const float4 w0 = w[0], w1 = w[1], w2 = w[2];
+                    const float lmn[3] = {w0.x, w0.y, w0.z}, lmx[3] = {w0.w, w1.x, w1.y};
+                    const float rmn[3] = {w1.z, w1.w, w2.x}, rmx[3] = {w2.y, w2.z, w2.w};
+                    float tl, tr;
+                    const bool hl = slab(lmn, lmx, ray.o, inv, tl) && tl <= current_t;
+                    const bool hr = slab(rmn, rmx, ray.o, inv, tr) && tr <= current_t;
+                    if (COUNT) { cnt.node_visits += 2; cnt.box_tests += 2; }
+                    const int k = cur_k, half = 1 << (k - 1);
+                    if (hl) {
+                        if (hr) { stack[__umul24((unsigned)(k - 1), (unsigned)nthreads)] = tr; pending |= 1u << k; }
+                        cur_k = k - 1;
+                        cur_id = cur_s + half - 1;
+                    } else if (hr) {
+                        const int sr = cur_s + half, e = min(cur_s + 2 * half - 1, n);
+                        cur_k = 32 - __clz(sr ^ e);
+                        cur_s = sr;
+                        cur_id = sr;
+                    } else {
+                        cur_k = K_POP;
+                    }
+                }
+        };
+        auto pop = [&]() {
+                if (cur_k == K_POP) {
+                    // one pending child per iteration; an entry whose entry distance no longer passes
+                    // the distance test is dropped and the lane tries again next iteration
+                    if (pending == 0) {
+                        cur_k = K_IDLE;
+                    } else {
+                        const int L = __ffs((int)pending) - 1;              // deepest pending ancestor level
+                        pending &= pending - 1;
+                        const float t_entry = stack[__umul24((unsigned)(L - 1), (unsigned)nthreads)];
+                        if (t_entry <= current_t) {
+                            const int sa = (cur_s >> L) << L, half = 1 << (L - 1);
+                            const int sr = sa + half, e = min(sa + 2 * half - 1, n);
+                            cur_k = 32 - __clz(sr ^ e);
+                            cur_s = sr;
+                            cur_id = sr;
+                        }
+                    }
+                }
+        };
+        for (;;) {
+            if (ballot64(cur_k >= K_POP) == 0) break;
+            if (__popcll(need_vote()) >= REFILL_T) break;
+            expand();
+            pop();
+            expand();
             const bool at_leaf = cur_k == 0;
             const unsigned long long leaf_mask = ballot64(at_leaf);
             if (leaf_mask != 0 && (__popcll(leaf_mask) >= LEAF_T || ballot64(cur_k >= 1) == 0)) {
@@ -670,24 +696,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                     cur_k = K_POP;
                 }
             }
-            if (cur_k == K_POP) {
-                // one pending child per iteration; an entry whose entry distance no longer passes
-                // the distance test is dropped and the lane tries again next iteration
-                if (pending == 0) {
-                    cur_k = K_IDLE;
-                } else {
-                    const int L = __ffs((int)pending) - 1;              // deepest pending ancestor level
-                    pending &= pending - 1;
-                    const float t_entry = stack[__umul24((unsigned)(L - 1), (unsigned)nthreads)];
-                    if (t_entry <= current_t) {
-                        const int sa = (cur_s >> L) << L, half = 1 << (L - 1);
-                        const int sr = sa + half, e = min(sa + 2 * half - 1, n);
-                        cur_k = 32 - __clz(sr ^ e);
-                        cur_s = sr;
-                        cur_id = sr;
-                    }
-                }
-            }
+            pop();
         }
         if (COUNT) sched[9] += (unsigned long long)((long long)__builtin_readcyclecounter() - t_trav);
     }
