@@ -380,6 +380,10 @@ __global__ __launch_bounds__(256) void k_path_seeds(int W, unsigned npix, uint32
 // K_NOITEM: holds no item.  One register and single comparisons, so that the wave votes of the
 // loop control are the comparison masks themselves.
 constexpr int K_POP = -1, K_IDLE = -2, K_NOITEM = -3;
+#ifndef PT_EXPANSIONS
+#define PT_EXPANSIONS 4
+#endif
+constexpr int EXPANSIONS = PT_EXPANSIONS;      // node expansions per pass of the traversal loop
 
 template <bool COUNT, bool LDSN>
 __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const TriIsect *__restrict__ tri_sorted, int levels,
@@ -661,8 +665,8 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
         for (;;) {
             if (ballot64(cur_k >= K_POP) == 0) break;
             if (__popcll(need_vote()) >= REFILL_T) break;
-            expand();
-            pop();
+#pragma unroll
+            for (int u = 0; u < EXPANSIONS - 1; u++) { expand(); pop(); }
             expand();
             const bool at_leaf = cur_k == 0;
             const unsigned long long leaf_mask = ballot64(at_leaf);
