@@ -616,7 +616,6 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                     sched[6] += __popcll(ballot64(cur_k == K_IDLE));                       // waiting for a refill
                     sched[7] += __popcll(ballot64(cur_k == K_NOITEM));                     // no item (queue empty)
                 }
-                iterations++;
                 if (cur_k >= 1) {                       // only traversing lanes have cur_k >= K_POP
                     const float4 *w = LDSN ? lds_nodes + __umul24((unsigned)cur_id, 3u)     // 24-bit multiply: full rate
                                            : reinterpret_cast<const float4 *>(sc.wide + cur_id);
@@ -665,6 +664,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
         for (;;) {
             if (ballot64(cur_k >= K_POP) == 0) break;
             if (__popcll(need_vote()) >= REFILL_T) break;
+            iterations += EXPANSIONS;
 #pragma unroll
             for (int u = 0; u < EXPANSIONS - 1; u++) { expand(); pop(); }
             expand();
