@@ -273,7 +273,7 @@ def main():
                          "kernel": "k_trace_persistent", "launch_ms_avg": kern_avg_ms,
                          "note": "algorithmic bytes (36 B per node visit + 36 B per triangle test) over kernel time; "
                                  "the node records live in LDS and the triangles in L1/L2, so these bytes never "
-                                 "reach HBM (see traffic): the kernel is VALU-issue bound, a fraction above 1 "
+                                 "reach HBM (see traffic): the kernel is bound by its per-wave instruction stream, a fraction above 1 "
                                  "only says the tree is served on chip"},
             "scene_build_ms": scene_build["total"],
         }
