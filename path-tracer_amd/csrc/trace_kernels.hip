@@ -80,7 +80,7 @@ __device__ __forceinline__ float rand_next(uint32_t &s)
 // (plane - origin) * (1/d) is evaluated on the pair with packed f32 math (two
 // IEEE operations per instruction; same results as the scalar form).
 typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ bool slab(const float *mn, const float *mx, const pt_f3 &o, const pt_f3 &inv, float &t_entry)
+__device__ __forceinline__ bool slab(const float *mn, const float *mx, const pt_f3 o, const pt_f3 inv, float &t_entry)
 {
     v2f bx, by, bz;
     if (inv.x >= 0) { bx.x = mn[0]; bx.y = mx[0]; } else { bx.x = mx[0]; bx.y = mn[0]; }

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptamd.so")
+# PTAMD_LIB selects another build of the same library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("PTAMD_LIB") or os.path.join(_HERE, "libptamd.so")
 
 # numpy views of the interchange structs (include/ptamd_structs.h)
 BOUND = np.dtype([("min", "<f4", 3), ("pad", "<f4"), ("max", "<f4", 3)])
