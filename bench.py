@@ -58,31 +58,58 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f4", "data": (ptr, False), "version": 2}
 
 
+def hbm_copy_gbs(nbytes=1 << 30, reps=10):
+    """Device-to-device copy rate (read + write bytes per second): what a plain streaming kernel reaches
+    on this GPU, beside the 8 TB/s of the data sheet."""
+    import torch
+    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    b = torch.empty_like(a)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    del a, b
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def bench_build(ctx_factory, n, reps):
     import ptamd
     ctx = ctx_factory()
     ctx.upload_primitives(soup(n))
-    times = []
-    for _ in range(reps + 1):
-        ctx.build()
-        times.append(ctx.build_times())
+
+    def median_times(flags):
+        times = []
+        for _ in range(reps + 1):
+            ctx.build(flags)
+            times.append(ctx.build_times())
+        times = times[1:]
+        return {k: sorted(t[k] for t in times)[len(times) // 2] for k in list(ptamd.STAGES) + ["total"]}
+
+    # the tree alone (bounds .. refit: what the 376 B/triangle model describes), and the default build,
+    # whose refit fetches the 80-byte primitives instead of the 32-byte boxes and also writes the two
+    # per-leaf records of the trace kernels
+    tree = median_times(ptamd.PT_BUILD_TREE_ONLY)
+    full = median_times(ptamd.PT_BUILD_DEFAULT)
     ctx.close()
-    times = times[1:]
-    # the tree: bounds .. refit (the bounds kernel also writes the per-triangle records of the trace
-    # kernels); `pack` = the records in leaf order, which only the trace kernels need
-    tot = sorted(t["total"] - t["pack"] for t in times)[len(times) // 2]
-    tot_all = sorted(t["total"] for t in times)[len(times) // 2]
-    med = {k: sorted(t[k] for t in times)[len(times) // 2] for k in ptamd.STAGES}
+    tot, tot_all = tree.pop("total"), full.pop("total")
     gbs = n * BUILD_BYTES_PER_TRI / (tot * 1e-3) / 1e9
+    copy_gbs = hbm_copy_gbs()
     return {
         "workload": f"{n} random triangles (soup), 15-bit codes, 2 radix passes",
         "mtris_per_s": n / (tot * 1e-3) / 1e6,
         "ms": tot,
         "ms_with_trace_records": tot_all,
-        "stage_ms": med,
+        "mtris_per_s_with_trace_records": n / (tot_all * 1e-3) / 1e6,
+        "stage_ms": tree,
+        "stage_ms_with_trace_records": full,
         "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": gbs / HBM_PEAK_GBS, "bytes_per_tri": BUILD_BYTES_PER_TRI,
-                     "traffic": build_traffic_from_profile(n)},
+                     "traffic": build_traffic_from_profile(n),
+                     "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": gbs / copy_gbs},
     }
 
 

@@ -71,6 +71,10 @@ int pt_set_constants(pt_context *ctx, const pt_CB_Radix *cb);
 #define PT_BUILD_KARRAS_LINKS   4u   /* pt_download_tree also runs the search-based link kernel (the direct
                                         counterpart of radix_build_cs.hlsl) over the links it has written from
                                         the closed form of the index-keyed tree -- same values */
+#define PT_BUILD_TREE_ONLY      8u   /* the tree and the sorted order only: the per-leaf triangle records of the
+                                        trace kernels are not written (the refit then gathers the 32-byte boxes
+                                        instead of the 80-byte primitives); pt_primary_hits, pt_intersect and
+                                        pt_trace* refuse until a build without this flag */
 int pt_build(pt_context *ctx, unsigned flags);
 
 typedef enum pt_build_stage {
@@ -78,9 +82,9 @@ typedef enum pt_build_stage {
     PT_STAGE_MORTON,       /* Morton codes                    */
     PT_STAGE_SORT,         /* radix sort (all passes)         */
     PT_STAGE_TOPOLOGY,     /* binary radix tree links         */
-    PT_STAGE_REFIT,        /* leaf init + bottom-up AABBs     */
-    PT_STAGE_PACK,         /* triangle records in leaf order for the trace kernels (the per-triangle
-                              records are written by the bounds stage) */
+    PT_STAGE_REFIT,        /* leaf init + bottom-up AABBs; unless PT_BUILD_TREE_ONLY also the per-leaf
+                              triangle records of the trace kernels (same fetch of the primitive) */
+    PT_STAGE_PACK,         /* the root's own box for the trace kernels */
     PT_STAGE_COUNT
 } pt_build_stage;
 /* device-side durations (ms, HIP events) of the last pt_build; total = sum.

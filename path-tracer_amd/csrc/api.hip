@@ -208,7 +208,7 @@ static int ensure_build_buffers(pt_context *ctx)
     if (!rc) rc = dev_alloc(ctx, &ctx->d_block_hist, 256 * nblocks);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_wide, (size_t)n);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_chunk, nchunks + (nchunks + 2047) / 2048 + 1);
-    if (!rc) rc = dev_alloc(ctx, &ctx->d_shade, (size_t)n);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_shade, (size_t)n + 1);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_tri_sorted, (size_t)n + 1);
     if (rc) { free_build(ctx); return rc; }
     ctx->capacity = n;
@@ -219,7 +219,7 @@ int pt_build(pt_context *ctx, unsigned flags)
 {
     if (!ctx) return PT_ERR_INVALID;
     if (!ctx->d_prims || ctx->n < 1) PT_FAIL(ctx, PT_ERR_INVALID, "pt_build: no primitives uploaded");
-    if (flags & ~(PT_BUILD_MORTON_FULL | PT_BUILD_KARRAS_LINKS)) PT_FAIL(ctx, PT_ERR_INVALID, "pt_build: unknown flag");
+    if (flags & ~(PT_BUILD_MORTON_FULL | PT_BUILD_KARRAS_LINKS | PT_BUILD_TREE_ONLY)) PT_FAIL(ctx, PT_ERR_INVALID, "pt_build: unknown flag");
     if (int rc = set_device(ctx)) return rc;
     if (int rc = ensure_build_buffers(ctx)) return rc;
     ctx->built = false;
@@ -410,6 +410,7 @@ void pt_albedo_bytes(const float kd[3], int srgb_quirk, uint8_t out_rgb[3])
 int pt_primary_hits(pt_context *ctx, const pt_camera *cam, const uint8_t *albedo_rgba8)
 {
     PT_NEED_BUILT(ctx, "pt_primary_hits");
+    if (!ctx->trace_records) PT_FAIL(ctx, PT_ERR_INVALID, "pt_primary_hits: the last build was PT_BUILD_TREE_ONLY");
     if (!cam || !albedo_rgba8) return PT_ERR_INVALID;
     if (!ctx->W) PT_FAIL(ctx, PT_ERR_INVALID, "pt_primary_hits: call pt_resize first");
     uint8_t *d_alb = nullptr;
@@ -458,6 +459,7 @@ void pt_frame_seeds(uint32_t base_seed, uint32_t first_frame, uint32_t count, ui
 static int check_trace_ready(pt_context *ctx, const char *who)
 {
     if (!ctx->built) PT_FAIL(ctx, PT_ERR_INVALID, std::string(who) + ": call pt_build first");
+    if (!ctx->trace_records) PT_FAIL(ctx, PT_ERR_INVALID, std::string(who) + ": the last build was PT_BUILD_TREE_ONLY");
     if (!ctx->have_cb) PT_FAIL(ctx, PT_ERR_INVALID, std::string(who) + ": call pt_set_constants first");
     if (ctx->cb.node_count != ctx->n) PT_FAIL(ctx, PT_ERR_INVALID, std::string(who) + ": CB_Radix.node_count differs from the primitive count");
     if (!ctx->W) PT_FAIL(ctx, PT_ERR_INVALID, std::string(who) + ": call pt_resize first");
@@ -635,6 +637,7 @@ int pt_reset_counters(pt_context *ctx)
 int pt_intersect(pt_context *ctx, const float *rays8, int n_rays, pt_hit *out)
 {
     PT_NEED_BUILT(ctx, "pt_intersect");
+    if (!ctx->trace_records) PT_FAIL(ctx, PT_ERR_INVALID, "pt_intersect: the last build was PT_BUILD_TREE_ONLY");
     if (!rays8 || !out || n_rays < 1) return PT_ERR_INVALID;
     float *d_rays = nullptr;
     pt_hit *d_out = nullptr;

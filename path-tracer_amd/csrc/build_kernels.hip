@@ -47,8 +47,7 @@ __device__ __forceinline__ float wave_max(float v)
 constexpr int PRIM_DW = 20;   // dwords per PrimitiveRender
 
 __global__ __launch_bounds__(256) void k_bounds(const uint4 *__restrict__ prims16, int n,
-                                                BoxRec *__restrict__ boxes, float *__restrict__ partial,
-                                                TriShade *__restrict__ shade)
+                                                BoxRec *__restrict__ boxes, float *__restrict__ partial)
 {
     __shared__ uint4 stage[256 * PRIM_DW / 4];      // 20480 B
     __shared__ float red[6][4];
@@ -77,13 +76,6 @@ __global__ __launch_bounds__(256) void k_bounds(const uint4 *__restrict__ prims1
         float4 *dst = reinterpret_cast<float4 *>(&boxes[first + t]);
         dst[0] = make_float4(b.mn[0], b.mn[1], b.mn[2], 0.0f);
         dst[1] = make_float4(b.mx[0], b.mx[1], b.mx[2], __int_as_float(b.index));
-        // the shading record of the trace kernels (the three normals and the material), while the
-        // primitive is at hand: a pass of its own would read the 80-byte records again
-        const int matid = reinterpret_cast<const int *>(p)[18];
-        float4 *ts = reinterpret_cast<float4 *>(&shade[first + t]);
-        ts[0] = make_float4(p[3], p[4], p[5], __int_as_float(matid));
-        ts[1] = make_float4(p[9], p[10], p[11], 0.0f);
-        ts[2] = make_float4(p[15], p[16], p[17], 0.0f);
     } else {
         const float inf = __uint_as_float(0x7f800000u);
 #pragma unroll
@@ -391,8 +383,17 @@ __device__ __forceinline__ void write_tree_node(pt_TreeNode *__restrict__ node, 
     dst[2] = make_float4(U[3], U[4], U[5], 0.0f);
 }
 
+// PACK: the lane fetches its primitive itself (the 80-byte record, by the permutation) instead of the
+// 32-byte box, evaluates the box with the expressions of k_bounds, and leaves the two records the trace
+// kernels read per leaf, in leaf order: {a, e1 = b - a, e2 = c - a, primitive id} and {normals, material}.
+// One random 80-byte fetch serves the refit and both records; a separate pass over the primitives would
+// fetch them again.  Key n, the out-of-range leaf, gets the records of primitive 0 (ray_tracing.hlsl:219-226
+// reads an all-zero node there: zero box, index 0).
+template <bool PACK>
 __global__ __launch_bounds__(PT_REFIT_CHUNK) void k_refit_low(const uint32_t *__restrict__ perm, const BoxRec *__restrict__ boxes,
-                                                   int n, WideNode *__restrict__ wide, ChunkBox *__restrict__ chunk)
+                                                   const uint4 *__restrict__ prims16,
+                                                   int n, WideNode *__restrict__ wide, ChunkBox *__restrict__ chunk,
+                                                   TriIsect *__restrict__ tri, TriShade *__restrict__ shade)
 {
     __shared__ float sb[6][PT_REFIT_CHUNK];          // 24 KB: min.xyz, max.xyz per key slot
     const int t = threadIdx.x;
@@ -401,7 +402,33 @@ __global__ __launch_bounds__(PT_REFIT_CHUNK) void k_refit_low(const uint32_t *__
         const int j = t;
         long long key = base + j;
         float b[6] = {0, 0, 0, 0, 0, 0};
-        if (key < n) {
+        if (PACK) {
+            if (key <= n) {
+                const int p = (key < n) ? (int)perm[key] : 0;
+                const float4 *src = reinterpret_cast<const float4 *>(prims16 + (size_t)p * (PRIM_DW / 4));
+                const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
+                // xyzn x 3: positions at floats 0..2, 6..8, 12..14, normals at 3..5, 9..11, 15..17, material at 18
+                const float A[3] = {v0.x, v0.y, v0.z}, B[3] = {v1.z, v1.w, v2.x}, C[3] = {v3.x, v3.y, v3.z};
+                if (key < n) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        // math3d.h:13-23, as in k_bounds
+                        const float x = A[k], y = B[k], z = C[k];
+                        const float yz_max = (y > z) ? y : z, yz_min = (y < z) ? y : z;
+                        b[3 + k] = (x > yz_max) ? x : yz_max;
+                        b[k] = (x < yz_min) ? x : yz_min;
+                    }
+                }
+                float4 *td = reinterpret_cast<float4 *>(&tri[key]);
+                td[0] = make_float4(A[0], A[1], A[2], __int_as_float(p));
+                td[1] = make_float4(B[0] - A[0], B[1] - A[1], B[2] - A[2], 0.0f);
+                td[2] = make_float4(C[0] - A[0], C[1] - A[1], C[2] - A[2], 0.0f);
+                float4 *sd = reinterpret_cast<float4 *>(&shade[key]);
+                sd[0] = make_float4(v0.w, v1.x, v1.y, v4.z);          // normal 0, material id (bits)
+                sd[1] = make_float4(v2.y, v2.z, v2.w, 0.0f);
+                sd[2] = make_float4(v3.w, v4.x, v4.y, 0.0f);
+            }
+        } else if (key < n) {
             const int p = (int)perm[key];
             const float4 *src = reinterpret_cast<const float4 *>(&boxes[p]);
             float4 lo = src[0], hi = src[1];
@@ -620,7 +647,7 @@ int ptk_build(pt_context *ctx, unsigned flags)
     const uint4 *prims16 = reinterpret_cast<const uint4 *>(ctx->d_prims);
 
     PT_HIP(ctx, hipEventRecord(ctx->ev[0], st));
-    hipLaunchKernelGGL(k_bounds, dim3(grid_n), dim3(256), 0, st, prims16, n, ctx->d_boxes, ctx->d_bbox_partial, ctx->d_shade);
+    hipLaunchKernelGGL(k_bounds, dim3(grid_n), dim3(256), 0, st, prims16, n, ctx->d_boxes, ctx->d_bbox_partial);
     hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(1024), 0, st, ctx->d_bbox_partial, grid_n, ctx->d_bbox_enc);
     PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_BOUNDS + 1], st));
 
@@ -655,7 +682,13 @@ int ptk_build(pt_context *ctx, unsigned flags)
     const uint32_t *perm = ctx->d_vals[ctx->sorted_buf];
     const int nchunks = (int)(((long long)n + 1 + PT_REFIT_CHUNK - 1) / PT_REFIT_CHUNK);
     const int top = bit_length((unsigned)n);
-    hipLaunchKernelGGL(k_refit_low, dim3(nchunks), dim3(PT_REFIT_CHUNK), 0, st, perm, ctx->d_boxes, n, ctx->d_wide, ctx->d_chunk);
+    const bool tree_only = (flags & PT_BUILD_TREE_ONLY) != 0;
+    if (tree_only)
+        hipLaunchKernelGGL(k_refit_low<false>, dim3(nchunks), dim3(PT_REFIT_CHUNK), 0, st, perm, ctx->d_boxes, prims16, n, ctx->d_wide,
+                           ctx->d_chunk, ctx->d_tri_sorted, ctx->d_shade);
+    else
+        hipLaunchKernelGGL(k_refit_low<true>, dim3(nchunks), dim3(PT_REFIT_CHUNK), 0, st, perm, ctx->d_boxes, prims16, n, ctx->d_wide,
+                           ctx->d_chunk, ctx->d_tri_sorted, ctx->d_shade);
     // levels above the chunks: groups of 2048 units per launch (two launches reach 2^32 keys)
     {
         const ChunkBox *in = ctx->d_chunk;
@@ -671,11 +704,11 @@ int ptk_build(pt_context *ctx, unsigned flags)
     }
     PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_REFIT + 1], st));
 
-    // records for the trace kernels: the per-triangle ones were written by the bounds kernel; what is
-    // left is the root's own box and the triangle records in leaf order
+    // the per-leaf records of the trace kernels were written by the refit (unless PT_BUILD_TREE_ONLY); what
+    // is left is the root's own box
     PT_HIP(ctx, hipGetLastError());
     if (int rc = ptk_root_box(ctx)) return rc;
-    if (int rc = ptk_sort_tris(ctx)) return rc;
+    ctx->trace_records = !tree_only;
     PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_PACK + 1], st));
     return PT_OK;
 }

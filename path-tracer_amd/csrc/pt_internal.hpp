@@ -24,16 +24,17 @@ struct __attribute__((aligned(16))) WideNode {
 };
 static_assert(sizeof(WideNode) == 64, "WideNode is four 16-byte loads");
 
-// Triangle record for intersection: vertex a and the two edges (b-a, c-a are
-// pure functions of the vertices, so precomputing them changes no result).
+// Per-leaf triangle record for intersection, in leaf-key order: vertex a and the two
+// edges (b-a, c-a are pure functions of the vertices, so precomputing them changes no
+// result), and the primitive id.
 struct __attribute__((aligned(16))) TriIsect {
-    float a[3];  int32_t matid;
+    float a[3];  int32_t prim;
     float e1[3]; float pad1;
     float e2[3]; float pad2;
 };
 static_assert(sizeof(TriIsect) == 48, "TriIsect is three 16-byte loads");
 
-// Triangle record for shading: the three vertex normals.
+// Per-leaf triangle record for shading, in leaf-key order: the three vertex normals and the material.
 struct __attribute__((aligned(16))) TriShade {
     float n0[3]; int32_t matid;
     float n1[3]; float pad1;
@@ -98,8 +99,9 @@ struct pt_context {
     WideNode *d_wide = nullptr;       // n
     ChunkBox *d_chunk = nullptr;      // ceil((n+1)/1024)
     float *d_root = nullptr;          // the root's own box (6 floats)
-    TriShade *d_shade = nullptr;      // n
-    TriIsect *d_tri_sorted = nullptr; // n+1, leaf-key order, primitive id in the spare word
+    TriShade *d_shade = nullptr;      // n+1, leaf-key order
+    TriIsect *d_tri_sorted = nullptr; // n+1, leaf-key order
+    bool trace_records = false;       // the two above were written by the last build (not PT_BUILD_TREE_ONLY)
     unsigned *d_work = nullptr;       // pixel queue head of the persistent trace kernel
     int num_cus = 256;
     int sort_passes = 0;
@@ -155,7 +157,6 @@ struct pt_context {
 // ---- launchers implemented in the kernel translation units ------------------
 int ptk_build(pt_context *ctx, unsigned flags);
 int ptk_root_box(pt_context *ctx);
-int ptk_sort_tris(pt_context *ctx);
 int ptk_order_pixels(pt_context *ctx, int shift);
 int ptk_export_sorted(pt_context *ctx, pt_PrimitiveRayCS *d_out);
 int ptk_export_tree(pt_context *ctx);

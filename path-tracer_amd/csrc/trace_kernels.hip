@@ -455,7 +455,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
     pt_f3 inv = pt_mk3(1, 1, 1);
     float current_t = 0;
     bool intersected = false;
-    int hit_prim = 0;
+    int hit_leaf = 0;
     float hit_bx = 0, hit_by = 0, hit_bz = 0;
 
     // the radiance sample of local frame fl (ray_tracing.hlsl:396-411: `multi` or black)
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                         if (intersected) {
                             ray.o = pt_add3(ray.o, pt_scale3(ray.d, current_t));
                             itr++;
-                            const float4 *shp = reinterpret_cast<const float4 *>(&sc.shade[hit_prim]);
+                            const float4 *shp = reinterpret_cast<const float4 *>(&sc.shade[hit_leaf]);
                             const float4 s0 = shp[0], s1 = shp[1], s2 = shp[2];
                             ended = false;
                             if (itr > MAX_ITR) {
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                             if (current_t > t && t > ray.t_min) {
                                 hit_bx = bx; hit_by = by; hit_bz = bz;
                                 current_t = t;
-                                hit_prim = __float_as_int(t0.w);
+                                hit_leaf = cur_s;          // the shading record is in leaf order too
                                 intersected = true;
                             }
                         }
@@ -747,7 +747,7 @@ struct PathRec {                 // 48 bytes
     float dx, dy, dz; uint32_t slot;      // slot = pixel * frames of the launch + local frame: the sample to write
     float mx, my, mz; int itr;
 };
-struct HitRec { float t; int prim; float bx, by; };   // prim < 0: no hit
+struct HitRec { float t; int leaf; float bx, by; };   // leaf key of the hit; < 0: no hit
 
 constexpr int WF_MAX_RAYS = MAX_ITR * 3 - 1;           // rays of the longest path
 
@@ -846,13 +846,13 @@ __global__ __launch_bounds__(256) void k_wf_shade(SceneView sc, const PathRec *_
             const float4 *src = reinterpret_cast<const float4 *>(&queue_in[seg_base + i]);
             const float4 r0 = src[0], r1 = src[1], r2 = src[2];
             const float4 h = reinterpret_cast<const float4 *>(hits)[seg_base + i];
-            const int prim = __float_as_int(h.y);
+            const int leaf = __float_as_int(h.y);                 // leaf key of the hit, -1 for a miss
             const uint32_t slot = __float_as_uint(r1.w);
             uint32_t seed = __float_as_uint(r0.w);
             pt_f3 multi = pt_mk3(r2.x, r2.y, r2.z);
             int itr = __float_as_int(r2.w);
             pt_f3 color = pt_mk3(0, 0, 0);
-            if (prim >= 0) {
+            if (leaf >= 0) {
                 // back from intersect() with a hit (ray_tracing.hlsl:372-395)
                 const pt_f3 d = pt_mk3(r1.x, r1.y, r1.z);
                 const pt_f3 o = pt_add3(pt_mk3(r0.x, r0.y, r0.z), pt_scale3(d, h.x));
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(SceneView sc, const PathRec *_
                 }
                 if (!ended && itr >= MAX_ITR * 3) ended = true;
                 if (!ended) {
-                    const float4 *shp = reinterpret_cast<const float4 *>(&sc.shade[prim]);
+                    const float4 *shp = reinterpret_cast<const float4 *>(&sc.shade[leaf]);
                     const float4 s0 = shp[0], s1 = shp[1], s2 = shp[2];
                     const float bx = h.z, by = h.w, bz = 1 - bx - by;
                     const pt_f3 A = pt_mk3(s0.x, s0.y, s0.z), B = pt_mk3(s1.x, s1.y, s1.z), C = pt_mk3(s2.x, s2.y, s2.z);
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
     ray.o = pt_mk3(0, 0, 0); ray.d = pt_mk3(0, 0, 1); ray.t_min = PT_EPSILON; ray.t_max = 10000;
     pt_f3 inv = pt_mk3(1, 1, 1);
     float current_t = 0;
-    int hit_prim = -1;
+    int hit_leaf = -1;
     float hit_bx = 0, hit_by = 0;
 
     for (;;) {
@@ -938,7 +938,7 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
         if (need_mask != 0 && (__popcll(need_mask) >= REFILL_T || trav_mask == 0)) {
             if (cur_k == K_IDLE && have) {
                 reinterpret_cast<float4 *>(hits)[ridx] =
-                    make_float4(current_t, __int_as_float(hit_prim), hit_bx, hit_by);
+                    make_float4(current_t, __int_as_float(hit_leaf), hit_bx, hit_by);
                 have = false;
             }
             bool want = cur_k == K_IDLE && !exhausted;
@@ -976,7 +976,7 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
                     ray.d = pt_mk3(r1.x, r1.y, r1.z);
                     inv = pt_mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
                     current_t = ray.t_max;
-                    hit_prim = -1;
+                    hit_leaf = -1;
                     pending = 0;
                     have = true;
                     cnt.rays++;
@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
                             if (current_t > t && t > ray.t_min) {
                                 hit_bx = bx; hit_by = by;
                                 current_t = t;
-                                hit_prim = __float_as_int(t0.w);
+                                hit_leaf = cur_s;          // the shading record is in leaf order too
                             }
                         }
                     }
@@ -1133,24 +1133,6 @@ __global__ __launch_bounds__(256) void k_accumulate(const float4 *__restrict__ s
             make_uchar4((unsigned char)to_unorm8(acc.x), (unsigned char)to_unorm8(acc.y),
                         (unsigned char)to_unorm8(acc.z), (unsigned char)to_unorm8(acc.w));
     }
-}
-
-// triangle records of the traversal ({a, e1 = b - a, e2 = c - a}) in leaf-key order, straight from the
-// primitives, the primitive id in the spare word; entry n belongs to the out-of-range leaf (primitive 0)
-__global__ __launch_bounds__(256) void k_sort_tris(const pt_PrimitiveRender *__restrict__ prims, const uint32_t *__restrict__ perm,
-                                                   int n, TriIsect *__restrict__ out)
-{
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j > n) return;
-    const int p = (j < n) ? (int)perm[j] : 0;
-    // xyzn x 3 = 20 floats: positions at floats 0..2, 6..8, 12..14; four 16-byte loads cover them
-    const float4 *src = reinterpret_cast<const float4 *>(&prims[p]);
-    const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-    const float a[3] = {v0.x, v0.y, v0.z};
-    float4 *dst = reinterpret_cast<float4 *>(&out[j]);
-    dst[0] = make_float4(a[0], a[1], a[2], __int_as_float(p));
-    dst[1] = make_float4(v1.z - a[0], v1.w - a[1], v2.x - a[2], 0.0f);
-    dst[2] = make_float4(v3.x - a[0], v3.y - a[1], v3.z - a[2], 0.0f);
 }
 
 // out = pow(sum.rgb / sum.a, 1/2.2), alpha 1
@@ -1282,14 +1264,6 @@ static size_t stack_bytes(const pt_context *ctx)
 {
     const int levels = 32 - __builtin_clz((unsigned)ctx->n | 1u);
     return (size_t)TRACE_THREADS * sizeof(uint2) * (size_t)(levels + 1 <= 16 ? 16 : 32);
-}
-
-int ptk_sort_tris(pt_context *ctx)
-{
-    hipLaunchKernelGGL(k_sort_tris, dim3((ctx->n + 1 + 255) / 256), dim3(256), 0, ctx->stream,
-                       ctx->d_prims, ctx->d_vals[ctx->sorted_buf], ctx->n, ctx->d_tri_sorted);
-    PT_HIP(ctx, hipGetLastError());
-    return PT_OK;
 }
 
 // Largest workgroup (multiple of 64, at most 1024 threads) whose per-level stack fits

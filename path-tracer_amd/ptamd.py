@@ -27,6 +27,7 @@ HIT = np.dtype([("hit", "<i4"), ("primitive", "<i4"), ("t", "<f4"), ("bary", "<f
 PT_BUILD_DEFAULT = 0
 PT_BUILD_MORTON_FULL = 1
 PT_BUILD_KARRAS_LINKS = 4
+PT_BUILD_TREE_ONLY = 8
 PT_ACCUM_LITERAL = 0
 PT_ACCUM_LINEAR = 1
 PT_SCHEDULE_PERSISTENT = 0

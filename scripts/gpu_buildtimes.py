@@ -9,7 +9,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 prims = make_soup(n, seed=12345, dtype=ptamd.PRIM_RENDER)
 ctx = ptamd.Context(0)
 ctx.upload_primitives(prims)
-for flags in (0, 0):
+for flags in (0, ptamd.PT_BUILD_TREE_ONLY, 0, ptamd.PT_BUILD_TREE_ONLY):
     best = None
     for _ in range(5):
         ctx.build(flags)

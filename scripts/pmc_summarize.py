@@ -10,6 +10,8 @@ for f in glob.glob(os.path.join(src, "*", "**", "*counter_collection.csv"), recu
         k = m.group(1) if m else name.replace("void ", "").split("(")[0].strip()
         if k in ("k_trace_persistent", "k_wf_extend") and (k + "<true") in name:
             k += "<detailed>"
+        if k == "k_refit_low" and "k_refit_low<true" in name:
+            k += "<pack>"          # the default build: the refit also writes the trace kernels' leaf records
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[k][r["Counter_Name"]] += 1
 res = {}
 for k in acc:

@@ -1,5 +1,5 @@
 """Small torch-free target for rocprofv3 counter passes: `trace` (scene04 1162x1008, 3 launches of
-128 frames, the benchmark's step) or `build` (10M-triangle soup, 3 builds)."""
+128 frames, the benchmark's step) or `build` (10M-triangle soup, 3 tree-only builds and 3 full builds)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,7 +26,8 @@ else:
     prims["vertices"]["pos"][:, 2] = c + (rng.random((n, 3), dtype=np.float32) * 2 - 1) * e
     prims["pad"] = -1
     ctx.upload_primitives(prims)
-    for _ in range(3):
-        ctx.build()
-    print(ctx.build_times())
+    for flags in (ptamd.PT_BUILD_TREE_ONLY, ptamd.PT_BUILD_DEFAULT):
+        for _ in range(3):
+            ctx.build(flags)
+        print(flags, ctx.build_times())
 ctx.close()

@@ -70,6 +70,28 @@ def test_closed_form_links_equal_search_kernel(gpu_ctx_factory, n):
         assert np.array_equal(a[f], o[f][:2 * n]), f
 
 
+@pytest.mark.parametrize("n", [1, 3, 1024, 1025, 2416, 300001])
+def test_tree_only_build_gives_the_same_tree_and_refuses_to_trace(gpu_ctx_factory, n):
+    """PT_BUILD_TREE_ONLY gathers boxes instead of primitives in the refit and writes no trace records:
+    same tree, same order; ray queries are refused until a full build."""
+    prims = make_soup(n, seed=77 + n)
+    ctx = gpu_ctx_factory()
+    ctx.upload_primitives(prims)
+    ctx.build()
+    full = ctx.tree().tobytes()
+    perm = ctx.permutation().copy()
+    ctx.build(ptamd.PT_BUILD_TREE_ONLY)
+    assert ctx.tree().tobytes() == full
+    assert np.array_equal(ctx.permutation(), perm)
+    rays = np.zeros((4, 8), np.float32)
+    rays[:, 5] = 1.0
+    rays[:, 7] = 10000.0
+    with pytest.raises(ptamd.PtError, match="TREE_ONLY"):
+        ctx.intersect(rays)
+    ctx.build()
+    ctx.intersect(rays)
+
+
 def test_rebuild_and_context_reuse(gpu_ctx_factory, golden):
     ctx = gpu_ctx_factory()
     for scene in ("scene04", "scene01", "scene04"):      # shrinking and growing n on one context
