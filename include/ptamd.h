@@ -168,6 +168,13 @@ int pt_output_device_ptr(pt_context *ctx, void **dev_rgba32f, void **dev_rgba8);
  * (default) traces any tree without asking.  Allowed: 0, 15, 32. */
 int pt_set_stack_size(pt_context *ctx, int entries);
 
+/* longest path, in rays after the G-buffer hit.  The reference ends a path when its counter `itr`
+ * (1 at the first bounce, +1 per hit) reaches MAX_ITR * 3 = 15, i.e. after 14 intersect() calls
+ * (ray_tracing.hlsl:245-247, 372-387).  0 (default) or 14 keeps that; 1..13 end paths earlier
+ * (NON-PARITY: the depth-limited configuration of large synthetic scenes).  Russian roulette still
+ * starts after itr > 5. */
+int pt_set_max_segments(pt_context *ctx, int segments);
+
 /* how pt_trace / pt_trace_frames schedule the paths of a launch on scenes whose tree fits
  * in LDS (larger scenes always use one kernel with the tree in global memory).  No
  * counterpart in the reference (one Dispatch per frame, ray_tracer.cpp:281-335); the

@@ -589,7 +589,7 @@ static pt_f3 second_tracing(const orc_scene *sc, uint32_t framecount,
             if (p > orc_rand_next(&seed)) multi = pt_scale3(multi, 1 / p);
             else return zero;
         }
-        if (itr >= ORC_MAX_ITR * 3) return zero;
+        if (itr >= (sc->max_segments > 0 ? sc->max_segments + 1 : ORC_MAX_ITR * 3)) return zero;
         pt_f3 A = ld3(&sc->prims[primitive_index].vertices[0].normal);
         pt_f3 B = ld3(&sc->prims[primitive_index].vertices[1].normal);
         pt_f3 C = ld3(&sc->prims[primitive_index].vertices[2].normal);

@@ -73,6 +73,7 @@ typedef struct orc_scene {
     const pt_TreeNode *tree;            /* 2n+1 */
     const pt_CB_Radix *cb;
     int stack_size;                     /* 15 = reference */
+    int max_segments;                   /* rays per path at most; 0 = reference (14: itr reaches MAX_ITR * 3) */
 } orc_scene;
 
 typedef struct orc_counters {

@@ -40,7 +40,7 @@ class Camera(C.Structure):
 
 class Scene(C.Structure):
     _fields_ = [("n", C.c_int), ("prims", C.c_void_p), ("tree", C.c_void_p), ("cb", C.c_void_p),
-                ("stack_size", C.c_int)]
+                ("stack_size", C.c_int), ("max_segments", C.c_int)]
 
 
 class Counters(C.Structure):
@@ -151,13 +151,13 @@ def albedo_table(cb, srgb_quirk=True, kd_override=None):
 class OracleScene:
     """Holds numpy buffers alive and exposes the C scene struct."""
 
-    def __init__(self, prims, tree, cb, stack_size=15):
+    def __init__(self, prims, tree, cb, stack_size=15, max_segments=0):
         self.prims = np.ascontiguousarray(prims, dtype=PRIM_RENDER)
         self.tree = np.ascontiguousarray(tree, dtype=TREENODE)
         self.cb = np.ascontiguousarray(cb, dtype=CB_RADIX)
         self.n = len(self.prims)
         assert len(self.tree) == 2 * self.n + 1
-        self.c = Scene(self.n, self.prims.ctypes.data, self.tree.ctypes.data, self.cb.ctypes.data, stack_size)
+        self.c = Scene(self.n, self.prims.ctypes.data, self.tree.ctypes.data, self.cb.ctypes.data, stack_size, max_segments)
 
 
 def primary(scene, cam, W, H, albedo8, threads=None):

@@ -568,6 +568,14 @@ int pt_set_stack_size(pt_context *ctx, int entries)
     return PT_OK;
 }
 
+int pt_set_max_segments(pt_context *ctx, int segments)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (segments < 0 || segments > 14) PT_FAIL(ctx, PT_ERR_INVALID, "pt_set_max_segments: 0 (reference: 14) or 1..14");
+    ctx->itr_limit = segments == 0 ? 15 : segments + 1;
+    return PT_OK;
+}
+
 int pt_set_trace_schedule(pt_context *ctx, int schedule)
 {
     if (!ctx) return PT_ERR_INVALID;

@@ -144,6 +144,7 @@ struct pt_context {
     // options / counters
     int stack_entries = 0;            // 0 = automatic
     int schedule = 0;                 // PT_SCHEDULE_*
+    int itr_limit = 15;               // a path ends when itr reaches it: max_segments + 1 (reference: MAX_ITR * 3)
     bool detailed = false;
     bool time_trace = false;          // record an event pair around the trace kernel of each launch
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;

@@ -327,7 +327,7 @@ constexpr int MAX_ITR = 5;   // ray_tracing.hlsl:245-247
 // Per lane the order of node visits, tests and random draws is exactly that of
 // the sequential loop, so results do not change.
 // ---------------------------------------------------------------------------
-struct Tuning { int refill_t, leaf_t; };
+struct Tuning { int refill_t, leaf_t; int itr_limit; };    // itr_limit: a path ends when itr reaches it (reference: MAX_ITR * 3)
 
 // ---------------------------------------------------------------------------
 // Path seeds of one launch: seed(pixel, frame) = rand_init(pixel id, g_random[0] of the frame)
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
     }
     __syncthreads();
 
-    const int REFILL_T = tune.refill_t, LEAF_T = tune.leaf_t;
+    const int REFILL_T = tune.refill_t, LEAF_T = tune.leaf_t, ITR_LIMIT = tune.itr_limit;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const unsigned npix = (unsigned)W * (unsigned)H;
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                                 if (pr > rand_next(seed)) multi = pt_scale3(multi, 1 / pr);
                                 else ended = true;
                             }
-                            if (!ended && itr >= MAX_ITR * 3) ended = true;
+                            if (!ended && itr >= ITR_LIMIT) ended = true;
                             if (!ended) {
                                 const pt_f3 A = pt_mk3(s0.x, s0.y, s0.z), B = pt_mk3(s1.x, s1.y, s1.z), C = pt_mk3(s2.x, s2.y, s2.z);
                                 b_normal = pt_add3(pt_add3(pt_scale3(A, hit_bz), pt_scale3(B, hit_bx)), pt_scale3(C, hit_by));
@@ -831,7 +831,8 @@ __global__ __launch_bounds__(256) void k_wf_shade(SceneView sc, const PathRec *_
                                                   const unsigned *__restrict__ count_in,
                                                   PathRec *__restrict__ queue_out, unsigned *__restrict__ count_out,
                                                   unsigned seg_size,
-                                                  float4 *__restrict__ samples, uint32_t first_frame, uint32_t count)
+                                                  float4 *__restrict__ samples, uint32_t first_frame, uint32_t count,
+                                                  int itr_limit)
 {
     // blockIdx.y = segment; the blocks of a segment stride over its records
     const unsigned seg = blockIdx.y;
@@ -863,7 +864,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(SceneView sc, const PathRec *_
                     if (pr > rand_next(seed)) multi = pt_scale3(multi, 1 / pr);
                     else ended = true;
                 }
-                if (!ended && itr >= MAX_ITR * 3) ended = true;
+                if (!ended && itr >= itr_limit) ended = true;
                 if (!ended) {
                     const float4 *shp = reinterpret_cast<const float4 *>(&sc.shade[leaf]);
                     const float4 s0 = shp[0], s1 = shp[1], s2 = shp[2];
@@ -1297,7 +1298,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
 {
     SceneView sv;
     if (int rc = make_view(ctx, sv)) return rc;
-    Tuning tune = {20, 16};
+    Tuning tune = {20, 16, ctx->itr_limit};
     if (const char *e = getenv("PTAMD_REFILL_T")) tune.refill_t = atoi(e);
     if (const char *e = getenv("PTAMD_LEAF_T")) tune.leaf_t = atoi(e);
     const bool lin = (mode == PT_ACCUM_LINEAR);
@@ -1360,7 +1361,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             PathRec *queue[2] = {static_cast<PathRec *>(ctx->d_wf_queue[0]), static_cast<PathRec *>(ctx->d_wf_queue[1])};
             HitRec *hits = static_cast<HitRec *>(ctx->d_wf_hits);
             const dim3 fgrid((unsigned)ctx->num_cus * 8u), sgrid(32, WF_SEGS);
-            Tuning wt = {16, 12};
+            Tuning wt = {16, 12, ctx->itr_limit};
             if (const char *e = getenv("PTAMD_WF_REFILL_T")) wt.refill_t = atoi(e);
             if (const char *e = getenv("PTAMD_WF_LEAF_T")) wt.leaf_t = atoi(e);
             if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream));
@@ -1368,7 +1369,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
                                ctx->d_world, first, cnt, seeds, ctx->d_samples, queue[0], qcount + per_depth, seg_size, ctx->d_counters);
             PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_extend<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_extend<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            for (int d = 1; d <= WF_MAX_RAYS; d++) {
+            for (int d = 1; d <= ctx->itr_limit - 1; d++) {          // a path is at most itr_limit - 1 rays long
                 PathRec *qin = queue[(d - 1) & 1], *qout = queue[d & 1];
                 if (ctx->detailed)
                     hipLaunchKernelGGL((k_wf_extend<true>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted,
@@ -1377,7 +1378,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
                     hipLaunchKernelGGL((k_wf_extend<false>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted,
                                        levels, qin, qcount + d * per_depth, seg_size, hits, qhead + d * per_depth, ctx->d_counters, wt);
                 hipLaunchKernelGGL(k_wf_shade, sgrid, dim3(256), 0, ctx->stream, sv, qin, hits, qcount + d * per_depth, qout,
-                                   qcount + (d + 1) * per_depth, seg_size, ctx->d_samples, first, cnt);
+                                   qcount + (d + 1) * per_depth, seg_size, ctx->d_samples, first, cnt, ctx->itr_limit);
             }
             if (ev_end) PT_HIP(ctx, hipEventRecord(ev_end, ctx->stream));
             PT_HIP(ctx, hipGetLastError());

@@ -45,7 +45,7 @@ EXPORTS = (
     "pt_trace", "pt_trace_frames", "pt_frame_seeds", "pt_get_frame_count", "pt_reset_accumulation",
     "pt_linear_sum_device_ptr", "pt_resolve",
     "pt_download_output", "pt_download_display", "pt_output_device_ptr",
-    "pt_set_stack_size", "pt_set_trace_schedule", "pt_set_trace_timing", "pt_get_trace_times", "pt_set_detailed_counters", "pt_get_counters", "pt_reset_counters", "pt_intersect",
+    "pt_set_stack_size", "pt_set_max_segments", "pt_set_trace_schedule", "pt_set_trace_timing", "pt_get_trace_times", "pt_set_detailed_counters", "pt_get_counters", "pt_reset_counters", "pt_intersect",
 )
 
 
@@ -281,6 +281,9 @@ class Context:
     # -- options / counters -------------------------------------------------
     def set_stack_size(self, entries):
         self._ck(self.L.pt_set_stack_size(self.h, C.c_int(entries)))
+
+    def set_max_segments(self, segments):
+        self._ck(self.L.pt_set_max_segments(self.h, C.c_int(segments)))
 
     def set_trace_schedule(self, schedule):
         self._ck(self.L.pt_set_trace_schedule(self.h, C.c_int(schedule)))

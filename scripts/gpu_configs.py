@@ -35,13 +35,15 @@ ctx.upload_primitives(prims); ctx.set_constants(soup_cb(n, eye=(50.0, 50.0, 300.
 for _ in range(2): ctx.build(ptamd.PT_BUILD_MORTON_FULL)
 print("soup build (full codes)", ctx.build_times(), flush=True)
 ctx.set_stack_size(32)
-ctx.resize(1920, 1080)
+if os.environ.get("DEPTH"): ctx.set_max_segments(int(os.environ["DEPTH"]))     # e.g. 8: the depth-limited 100M configuration
+SW, SH = int(os.environ.get("SOUP_W", 1920)), int(os.environ.get("SOUP_H", 1080))
+ctx.resize(SW, SH)
 kd = [[0.7, 0.6, 0.5]] * 16
 cam = ptamd.default_camera(eye=(50.0, 50.0, 300.0), at=(50.0, 50.0, 50.0)); cam.zfar = 1000.0
 ctx.primary_hits(cam, ptamd.albedo_table(kd))
-run(ctx, 1920, 1080, 4, f"soup {n} (21-bit codes)"); run(ctx, 1920, 1080, 4, f"soup {n} (21-bit codes)")
+run(ctx, SW, SH, 4, f"soup {n} (21-bit codes)"); run(ctx, SW, SH, 4, f"soup {n} (21-bit codes)")
 for _ in range(2): ctx.build()
 print("soup build (reference codes)", ctx.build_times(), flush=True)
 ctx.primary_hits(cam, ptamd.albedo_table(kd))
-run(ctx, 1920, 1080, 1, f"soup {n} (reference 22-level codes)")
+run(ctx, SW, SH, 1, f"soup {n} (reference 22-level codes)")
 ctx.close()

@@ -208,3 +208,19 @@ def test_frame_is_deterministic_and_seed_sensitive(golden):
     c = orc.trace_frame(sc, gb, 0, 124, z)[0]
     assert a.tobytes() == b.tobytes()
     assert a.tobytes() != c.tobytes()
+
+
+def test_max_segments_limits_the_path_length(golden):
+    """max_segments = 0 and 14 are the reference's limit (itr reaches MAX_ITR * 3 after 14 rays,
+    ray_tracing.hlsl:245-247,372-387); a smaller value ends every path after that many rays."""
+    W, H = 48, 40
+    sc, gb = _small_scene(golden, "scene04", W, H)
+    g = golden["scene04"]
+    z = np.zeros((H, W, 4), np.float32)
+    ref = orc.trace_frame(sc, gb, 0, 123, z)
+    same = orc.trace_frame(orc.OracleScene(g["prims"], g["tree"], g["cb"], max_segments=14), gb, 0, 123, z)
+    assert ref[0].tobytes() == same[0].tobytes() and ref[3] == same[3]
+    for cap in (1, 3):
+        out = orc.trace_frame(orc.OracleScene(g["prims"], g["tree"], g["cb"], max_segments=cap), gb, 0, 123, z)
+        assert out[3]["rays"] <= cap * out[3]["paths"]
+        assert out[3]["rays"] < ref[3]["rays"]

@@ -82,6 +82,37 @@ def test_frames_bit_exact_literal(gpu_ctx_factory, golden, scene, schedule):
 
 
 @pytest.mark.parametrize("schedule", SCHEDULES)
+@pytest.mark.parametrize("segments", [1, 3, 8, 14])
+def test_max_segments_bit_exact(gpu_ctx_factory, golden, schedule, segments):
+    """pt_set_max_segments (the depth cap of the large synthetic configuration): paths end after that many
+    rays, in the library and in the oracle alike; 14 is the reference's own limit."""
+    W, H = 96, 80
+    g = golden["scene04"]
+    ctx = gpu_ctx_factory()
+    ctx.set_trace_schedule(schedule)
+    _, gb, _ = _setup(ctx, g, W, H)
+    ctx.set_max_segments(segments)
+    ctx.set_detailed_counters(True)
+    sc = orc.OracleScene(g["prims"], g["tree"], g["cb"], max_segments=segments)
+    seeds = ptamd.frame_seeds(1, 0, 4)
+    ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LITERAL)
+    old = np.zeros((H, W, 4), np.float32)
+    tot = dict(paths=0, rays=0, node_visits=0, box_tests=0, tri_tests=0)
+    for f in range(4):
+        old, _, _, c = orc.trace_frame(sc, gb, f, seeds[f], old)
+        tot = {k: tot[k] + c[k] for k in tot}
+    assert np.array_equal(_bits(ctx.output()), _bits(old))
+    assert ctx.counters() == tot
+    assert tot["rays"] <= segments * tot["paths"]
+    if segments == 14:
+        ref = orc.OracleScene(g["prims"], g["tree"], g["cb"])
+        assert np.array_equal(_bits(orc.trace_frame(ref, gb, 0, seeds[0], np.zeros((H, W, 4), np.float32))[0]),
+                              _bits(orc.trace_frame(sc, gb, 0, seeds[0], np.zeros((H, W, 4), np.float32))[0]))
+    with pytest.raises(ptamd.PtError):
+        ctx.set_max_segments(15)
+
+
+@pytest.mark.parametrize("schedule", SCHEDULES)
 @pytest.mark.parametrize("scene", ["scene01", "scene04"])
 def test_frames_bit_exact_linear_and_late_frames(gpu_ctx_factory, golden, scene, schedule):
     """Linear-sum mode, starting at a late frame index so that all stratification bits of
