@@ -993,10 +993,9 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
             }
         }
         // --------------------------------------------------------- traversal
-        for (;;) {
-            const bool trav = cur_k >= K_POP;
-            if (ballot64(trav) == 0) break;
-            if (__popcll(ballot64(cur_k == K_IDLE && (have || !exhausted))) >= REFILL_T) break;
+        // as in k_trace_persistent: EXPANSIONS node expansions per loop pass, each followed by a pop
+        // attempt; loop control and the triangle-test decision once per pass
+        auto expand = [&]() {
             if (cur_k >= 1) {                       // only traversing lanes have cur_k >= K_POP
                 const float4 *w = lds_nodes + __umul24((unsigned)cur_id, 3u);   // 24-bit multiply: full rate
                 const float4 w0 = w[0], w1 = w[1], w2 = w[2];
@@ -1020,6 +1019,33 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
                     cur_k = K_POP;
                 }
             }
+        };
+        auto pop = [&]() {
+            if (cur_k == K_POP) {
+                // one pending child per iteration; an entry whose entry distance no longer passes
+                // the distance test is dropped and the lane tries again next iteration
+                if (pending == 0) {
+                    cur_k = K_IDLE;
+                } else {
+                    const int L = __ffs((int)pending) - 1;              // deepest pending ancestor level
+                    pending &= pending - 1;
+                    const float t_entry = stack[__umul24((unsigned)(L - 1), (unsigned)nthreads)];
+                    if (t_entry <= current_t) {
+                        const int sa = (cur_s >> L) << L, half = 1 << (L - 1);
+                        const int sr = sa + half, e = min(sa + 2 * half - 1, n);
+                        cur_k = 32 - __clz(sr ^ e);
+                        cur_s = sr;
+                        cur_id = sr;
+                    }
+                }
+            }
+        };
+        for (;;) {
+            if (ballot64(cur_k >= K_POP) == 0) break;
+            if (__popcll(ballot64(cur_k == K_IDLE && (have || !exhausted))) >= REFILL_T) break;
+#pragma unroll
+            for (int u = 0; u < EXPANSIONS - 1; u++) { expand(); pop(); }
+            expand();
             const bool at_leaf = cur_k == 0;
             const unsigned long long leaf_mask = ballot64(at_leaf);
             if (leaf_mask != 0 && (__popcll(leaf_mask) >= LEAF_T || ballot64(cur_k >= 1) == 0)) {
@@ -1050,24 +1076,7 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
                     cur_k = K_POP;
                 }
             }
-            if (cur_k == K_POP) {
-                // one pending child per iteration; an entry whose entry distance no longer passes
-                // the distance test is dropped and the lane tries again next iteration
-                if (pending == 0) {
-                    cur_k = K_IDLE;
-                } else {
-                    const int L = __ffs((int)pending) - 1;              // deepest pending ancestor level
-                    pending &= pending - 1;
-                    const float t_entry = stack[__umul24((unsigned)(L - 1), (unsigned)nthreads)];
-                    if (t_entry <= current_t) {
-                        const int sa = (cur_s >> L) << L, half = 1 << (L - 1);
-                        const int sr = sa + half, e = min(sa + 2 * half - 1, n);
-                        cur_k = 32 - __clz(sr ^ e);
-                        cur_s = sr;
-                        cur_id = sr;
-                    }
-                }
-            }
+            pop();
         }
     }
     flush_counters(cnt, counters, COUNT);
