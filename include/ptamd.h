@@ -65,7 +65,9 @@ int pt_set_constants(pt_context *ctx, const pt_CB_Radix *cb);
  * codes, sort, strip: ray_tracer.cpp:41-66), RayTracer::buildRadixTree
  * (ray_tracer.cpp:263-269 -> radix_build_cs.hlsl) and RayTracer::buildBVH
  * (ray_tracer.cpp:271-279 -> bvh_build_cs.hlsl).
- * Equal Morton codes keep ascending primitive index (stable sort). */
+ * Equal Morton codes keep ascending primitive index (stable sort).  An axis on which the scene box
+ * is flat (0/0 in structs.hpp:92-97) quantises to cell 0, which is what the reference's x86 float ->
+ * integer conversion leaves in the bits it interleaves. */
 #define PT_BUILD_DEFAULT        0u
 #define PT_BUILD_MORTON_FULL    1u   /* NON-PARITY: quantise to 2^21 cells per axis instead of the reference's 22 */
 #define PT_BUILD_KARRAS_LINKS   4u   /* pt_download_tree also runs the search-based link kernel (the direct

@@ -166,9 +166,15 @@ uint64_t orc_morton(const pt_Bound *sb, const pt_Bound *bb)
     float midy = (sb->min.v[1] + sb->max.v[1]) / 2;
     float midz = (sb->min.v[2] + sb->max.v[2]) / 2;
     const int L = PT_MORTON_CODE_LENGTH_EACH;
-    uint64_t a = (uint64_t)(((midx - min_x) / (max_x - min_x)) * L);
-    uint64_t b = (uint64_t)(((midy - min_y) / (max_y - min_y)) * L);
-    uint64_t c = (uint64_t)(((midz - min_z) / (max_z - min_z)) * L);
+    /* An axis on which the scene box is flat gives 0/0 = NaN, and converting NaN to an integer is
+     * undefined in C.  x86 (the reference's platform) converts it to 0x8000000000000000, of which the
+     * interleave below uses bits 21..0: zero.  That value is made explicit here. */
+    float qa = ((midx - min_x) / (max_x - min_x)) * L;
+    float qb = ((midy - min_y) / (max_y - min_y)) * L;
+    float qc = ((midz - min_z) / (max_z - min_z)) * L;
+    uint64_t a = (qa != qa) ? 0 : (uint64_t)qa;
+    uint64_t b = (qb != qb) ? 0 : (uint64_t)qb;
+    uint64_t c = (qc != qc) ? 0 : (uint64_t)qc;
     for (int j = 0; j < L; j++) {
         code |= (((a >> (L - 1 - j)) & 1) << ((L - j) * 3 - 1)) |
                 (((b >> (L - 1 - j)) & 1) << ((L - j) * 3 - 2)) |

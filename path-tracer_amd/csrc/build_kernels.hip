@@ -147,9 +147,14 @@ __global__ __launch_bounds__(256) void k_morton(const BoxRec *__restrict__ boxes
     float midx = (lo.x + hi.x) / 2;
     float midy = (lo.y + hi.y) / 2;
     float midz = (lo.z + hi.z) / 2;
-    uint64_t a = (uint64_t)(((midx - min_x) / (max_x - min_x)) * cells);
-    uint64_t b = (uint64_t)(((midy - min_y) / (max_y - min_y)) * cells);
-    uint64_t c = (uint64_t)(((midz - min_z) / (max_z - min_z)) * cells);
+    // a flat axis of the scene box gives 0/0 = NaN: cell 0 (what the x86 conversion of the reference
+    // leaves in the bits it interleaves)
+    const float qa = ((midx - min_x) / (max_x - min_x)) * cells;
+    const float qb = ((midy - min_y) / (max_y - min_y)) * cells;
+    const float qc = ((midz - min_z) / (max_z - min_z)) * cells;
+    uint64_t a = (qa != qa) ? 0 : (uint64_t)qa;
+    uint64_t b = (qb != qb) ? 0 : (uint64_t)qb;
+    uint64_t c = (qc != qc) ? 0 : (uint64_t)qc;
     codes[i] = (K)((spread3(a) << 2) | (spread3(b) << 1) | spread3(c));
 }
 

@@ -103,6 +103,22 @@ def test_rebuild_and_context_reuse(gpu_ctx_factory, golden):
         assert np.array_equal(t["left"], g["tree"]["left"][:-1])
 
 
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_flat_scene_box_axis_quantises_to_cell_zero(gpu_ctx_factory, axis):
+    """All vertices in one plane: (mid - min) / (max - min) is 0/0 on that axis.  The reference's x86
+    conversion leaves zero in the bits it interleaves; library and oracle define the same."""
+    n = 3000
+    prims = make_soup(n, seed=31 + axis)
+    prims["vertices"]["pos"][:, :, axis] = np.float32(0.25)
+    ctx = gpu_ctx_factory()
+    ctx.upload_primitives(prims)
+    ctx.build()
+    ob = orc.build(prims)
+    _assert_build_equals(ctx, ob)
+    bit = 2 - axis                                      # x is the highest bit of each triple
+    assert not np.any(ctx.morton() & np.uint64(sum(1 << (3 * k + bit) for k in range(21))))
+
+
 def test_heavy_ties_are_stable(gpu_ctx_factory):
     """All triangles in one Morton cell but one: the order of equal codes is ascending index."""
     n = 5000

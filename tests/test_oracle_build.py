@@ -164,3 +164,17 @@ def test_morton_bit_layout():
     assert code((0, 1 / 21 + 1e-4, 0)) == 2          # b = 1 -> bit 1
     assert code((0, 0, 1 / 21 + 1e-4)) == 1          # c = 1 -> bit 0
     assert code((1, 1, 1)) == 0b111_000_111_000_111  # 21 = 0b10101 on every axis
+
+
+def test_morton_flat_axis_is_cell_zero():
+    """A scene box that is flat on an axis gives 0/0 there; the x86 conversion the reference relies on
+    leaves zero in the 22 bits that are interleaved (structs.hpp:81-105), and so does the oracle."""
+    import ctypes as C
+    big = np.zeros(1, dtype=orc.BOUND)
+    big["min"][0] = (0, 0.5, 0)
+    big["max"][0] = (1, 0.5, 1)                       # flat in y
+    small = np.zeros(1, dtype=orc.BOUND)
+    small["min"][0] = (1, 0.5, 1)
+    small["max"][0] = (1, 0.5, 1)
+    code = orc.lib().orc_morton(small.ctypes.data_as(C.c_void_p), big.ctypes.data_as(C.c_void_p))
+    assert code == 0b101_000_101_000_101              # 21 on x and z, 0 on y
