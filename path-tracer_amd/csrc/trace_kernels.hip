@@ -76,21 +76,18 @@ __device__ __forceinline__ float rand_next(uint32_t &s)
 // ray_tracing.hlsl:46-86 with the reciprocal direction hoisted out (it is a pure
 // function of the ray).  Returns t_min <= t_max; the caller compares entry
 // distance with the current hit distance.  Per axis the (near, far) plane pair
-// is selected by the sign test on 1/d exactly as the shader does, then
-// (plane - origin) * (1/d) is evaluated on the pair with packed f32 math (two
-// IEEE operations per instruction; same results as the scalar form).
-typedef float v2f __attribute__((ext_vector_type(2)));
+// is selected by the sign test on 1/d exactly as the shader does.  Plain scalar
+// f32 arithmetic on purpose: the packed forms (v_pk_add_f32 / v_pk_mul_f32, which
+// the SLP vectoriser also produces on its own; the library is built without it)
+// made the traversal loop 6.5 % slower.
 __device__ __forceinline__ bool slab(const float *mn, const float *mx, const pt_f3 o, const pt_f3 inv, float &t_entry)
 {
-    v2f bx, by, bz;
-    if (inv.x >= 0) { bx.x = mn[0]; bx.y = mx[0]; } else { bx.x = mx[0]; bx.y = mn[0]; }
-    if (inv.y >= 0) { by.x = mn[1]; by.y = mx[1]; } else { by.x = mx[1]; by.y = mn[1]; }
-    if (inv.z >= 0) { bz.x = mn[2]; bz.y = mx[2]; } else { bz.x = mx[2]; bz.y = mn[2]; }
-    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-    const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
-    const v2f tx = (bx - ox) * ix, ty = (by - oy) * iy, tz = (bz - oz) * iz;
-    float t_min = pt_max(tx.x, pt_max(ty.x, tz.x));
-    float t_max = pt_min(tx.y, pt_min(ty.y, tz.y));
+    float nx, fx, ny, fy, nz, fz;
+    if (inv.x >= 0) { nx = mn[0]; fx = mx[0]; } else { nx = mx[0]; fx = mn[0]; }
+    if (inv.y >= 0) { ny = mn[1]; fy = mx[1]; } else { ny = mx[1]; fy = mn[1]; }
+    if (inv.z >= 0) { nz = mn[2]; fz = mx[2]; } else { nz = mx[2]; fz = mn[2]; }
+    float t_min = pt_max((nx - o.x) * inv.x, pt_max((ny - o.y) * inv.y, (nz - o.z) * inv.z));
+    float t_max = pt_min((fx - o.x) * inv.x, pt_min((fy - o.y) * inv.y, (fz - o.z) * inv.z));
     t_entry = t_min;
     return t_min <= t_max;
 }

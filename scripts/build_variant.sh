@@ -5,6 +5,6 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; src=$2; shift 2
 mkdir -p "$ROOT/ab"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -I"$ROOT/path-tracer_amd/csrc" -I"$ROOT/include" "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -I"$ROOT/path-tracer_amd/csrc" -I"$ROOT/include" "$@" \
     -shared -o "$ROOT/ab/$name.so" "$ROOT/path-tracer_amd/csrc/api.hip" "$ROOT/path-tracer_amd/csrc/build_kernels.hip" "$src"
 echo "built ab/$name.so"
