@@ -623,19 +623,15 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                     const bool hl = slab(lmn, lmx, ray.o, inv, tl) && tl <= current_t;
                     const bool hr = slab(rmn, rmx, ray.o, inv, tr) && tr <= current_t;
                     if (COUNT) { cnt.node_visits += 2; cnt.box_tests += 2; }
+                    // the right child (first key sr, level kr) is worked out whether or not it is taken: selects
+                    // instead of nested branches shorten the wave's instruction stream
                     const int k = cur_k, half = 1 << (k - 1);
-                    if (hl) {
-                        if (hr) { stack[__umul24((unsigned)(k - 1), (unsigned)nthreads)] = tr; pending |= 1u << k; }
-                        cur_k = k - 1;
-                        cur_id = cur_s + half - 1;
-                    } else if (hr) {
-                        const int sr = cur_s + half, e = min(cur_s + 2 * half - 1, n);
-                        cur_k = 32 - __clz(sr ^ e);
-                        cur_s = sr;
-                        cur_id = sr;
-                    } else {
-                        cur_k = K_POP;
-                    }
+                    const int sr = cur_s + half, e = min(sr + half - 1, n);
+                    const int kr = 32 - __clz(sr ^ e);
+                    if (hl && hr) { stack[__umul24((unsigned)(k - 1), (unsigned)nthreads)] = tr; pending |= 1u << k; }
+                    cur_k = hl ? k - 1 : (hr ? kr : K_POP);
+                    cur_id = hl ? sr - 1 : sr;
+                    cur_s = hl ? cur_s : sr;          // after a double miss only the bits above the pending levels matter
                 }
         };
         auto pop = [&]() {
@@ -1003,18 +999,12 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
                 const bool hr = slab(rmn, rmx, ray.o, inv, tr) && tr <= current_t;
                 if (COUNT) { cnt.node_visits += 2; cnt.box_tests += 2; }
                 const int k = cur_k, half = 1 << (k - 1);
-                if (hl) {
-                    if (hr) { stack[__umul24((unsigned)(k - 1), (unsigned)nthreads)] = tr; pending |= 1u << k; }
-                    cur_k = k - 1;
-                    cur_id = cur_s + half - 1;
-                } else if (hr) {
-                    const int sr = cur_s + half, e = min(cur_s + 2 * half - 1, n);
-                    cur_k = 32 - __clz(sr ^ e);
-                    cur_s = sr;
-                    cur_id = sr;
-                } else {
-                    cur_k = K_POP;
-                }
+                const int sr = cur_s + half, e = min(sr + half - 1, n);
+                const int kr = 32 - __clz(sr ^ e);
+                if (hl && hr) { stack[__umul24((unsigned)(k - 1), (unsigned)nthreads)] = tr; pending |= 1u << k; }
+                cur_k = hl ? k - 1 : (hr ? kr : K_POP);
+                cur_id = hl ? sr - 1 : sr;
+                cur_s = hl ? cur_s : sr;
             }
         };
         auto pop = [&]() {
@@ -1304,7 +1294,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
 {
     SceneView sv;
     if (int rc = make_view(ctx, sv)) return rc;
-    Tuning tune = {20, 16, ctx->itr_limit};
+    Tuning tune = {20, 12, ctx->itr_limit};
     if (const char *e = getenv("PTAMD_REFILL_T")) tune.refill_t = atoi(e);
     if (const char *e = getenv("PTAMD_LEAF_T")) tune.leaf_t = atoi(e);
     const bool lin = (mode == PT_ACCUM_LINEAR);
