@@ -1303,6 +1303,10 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
     size_t lds_bytes = 0;
     int threads = lds_resident_threads(ctx, &levels, &lds_bytes);
     if (const char *e = getenv("PTAMD_NO_LDS_TREE")) if (atoi(e)) threads = 0;
+    if (const char *e = getenv("PTAMD_MAX_THREADS")) {      // occupancy experiments: fewer waves per CU
+        const int cap = (atoi(e) / 64) * 64;
+        if (cap >= 256 && threads > cap) { lds_bytes -= (size_t)levels * 4 * (size_t)(threads - cap); threads = cap; }
+    }
     const bool lds_nodes = threads >= 256;          // else: node records stay in global memory
     if (!lds_nodes) {
         // LDS holds the materials and one float per tree level and lane
