@@ -603,7 +603,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
         }
         const long long t_trav = COUNT ? (long long)__builtin_readcyclecounter() : 0;
         // --------------------------------------------------------- traversal
-        // One loop pass = two node expansions, each followed by a pop attempt, with the loop control
+        // One loop pass = EXPANSIONS node expansions, each followed by a pop attempt, with the loop control
         // and the triangle-test decision once per pass (they cost as much as a fifth of an expansion).
         auto expand = [&]() {
                 if (COUNT) {
