@@ -206,7 +206,8 @@ int pt_reset_counters(pt_context *ctx);
  * last pt_get_trace_times): HIP events on the context's stream around the persistent trace kernel
  * alone (PT_SCHEDULE_WAVEFRONT: around the first-bounce .. last shading kernel), not around the
  * accumulate or queue-order kernels.  pt_get_trace_times synchronises, writes at most `capacity`
- * durations (ms, oldest first), returns how many launches were timed in *count and forgets them.
+ * durations (ms, oldest first), returns how many launches were timed in *count and forgets them;
+ * the latest 4096 launches are kept when nobody reads.
  * No counterpart in the reference. */
 int pt_set_trace_timing(pt_context *ctx, int enabled);
 int pt_get_trace_times(pt_context *ctx, float *ms, int capacity, int *count);

@@ -1347,6 +1347,12 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
         const uint32_t *seeds = ctx->d_seeds + off;
         hipEvent_t ev_begin = nullptr, ev_end = nullptr;
         if (ctx->time_trace) {
+            // bounded history: a caller that never reads the times keeps the latest 4096 launches
+            if (ctx->trace_events.size() >= 4096) {
+                (void)hipEventDestroy(ctx->trace_events.front().first);
+                (void)hipEventDestroy(ctx->trace_events.front().second);
+                ctx->trace_events.erase(ctx->trace_events.begin());
+            }
             PT_HIP(ctx, hipEventCreate(&ev_begin));
             PT_HIP(ctx, hipEventCreate(&ev_end));
             ctx->trace_events.emplace_back(ev_begin, ev_end);
