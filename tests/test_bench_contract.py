@@ -1,0 +1,54 @@
+"""CPU: the benchmark's output contract, checked on the committed record of the last GPU run
+(profiles/r01_bench_default.json) and on bench.py's command line."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_every_contract_field():
+    line = open(os.path.join(ROOT, "profiles", "r01_bench_default.json")).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "Mrays/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None                       # the reference publishes no number for this metric
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port")
+    # value = rays of all steps / wall time: consistent with ms_per_step and the ray statistics
+    rays = d["value"] * 1e6 * d["ms_per_step"] * 1e-3 * d["steps"]
+    paths = d["mpaths_per_s"] * 1e6 * d["ms_per_step"] * 1e-3 * d["steps"]
+    assert abs(rays / paths - d["rays_per_path"]) < 1e-6 * d["rays_per_path"]
+    b = d["build"]
+    assert abs(b["roofline"]["frac"] - b["roofline"]["achieved"] / b["roofline"]["peak"]) < 1e-9
+    assert abs(b["mtris_per_s"] - 10_000_000 / (b["ms"] * 1e-3) / 1e6) < 1e-6 * b["mtris_per_s"]
+
+
+def test_kernel_stats_agree_with_the_bench_line():
+    """The profiler's average duration of the trace kernel and the HIP-event time inside bench.py
+    come from the same run and must agree."""
+    import csv
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r01_bench_default.json")).read().strip().splitlines()[-1])
+    avg = None
+    for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_bench_default_kernel_stats.csv"))):
+        if "k_trace_persistent<false, true>" in r["Name"]:
+            avg = float(r["AverageNs"]) * 1e-6
+    assert avg is not None
+    assert abs(avg - d["roofline"]["launch_ms_avg"]) < 0.01 * avg
+
+
+def test_bench_command_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in out.stdout
