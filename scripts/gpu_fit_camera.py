@@ -43,15 +43,26 @@ def cost(p):
 
 p0 = np.array([0.0, 5.0, 23.0, 0.0, 5.0, 0.0])
 t = time.time()
-print("default camera: rmse4", round(cost(p0), 3), flush=True)
-simplex = np.vstack([p0] + [p0 + d for d in np.diag([0.3, 0.3, 1.0, 0.3, 0.3, 0.3])])
-res = minimize(cost, p0, method="Nelder-Mead", options={"initial_simplex": simplex, "xatol": 2e-3, "fatol": 2e-3, "maxfev": 500})
-p = res.x
-print(f"fitted camera eye {np.round(p[:3], 4)} at {np.round(p[3:], 4)} rmse4 {res.fun:.3f} after {evals[0]} renders, {time.time() - t:.0f} s", flush=True)
+if os.environ.get("POSE"):        # POSE="ex ey ez ax ay az": skip the fit
+    p = np.array([float(x) for x in os.environ["POSE"].split()])
+else:
+    print("default camera: rmse4", round(cost(p0), 3), flush=True)
+    simplex = np.vstack([p0] + [p0 + d for d in np.diag([0.3, 0.3, 1.0, 0.3, 0.3, 0.3])])
+    res = minimize(cost, p0, method="Nelder-Mead", options={"initial_simplex": simplex, "xatol": 2e-3, "fatol": 2e-3, "maxfev": 500})
+    p = res.x
+    print(f"fitted camera eye {np.round(p[:3], 4)} at {np.round(p[3:], 4)} rmse4 {res.fun:.3f} after {evals[0]} renders, {time.time() - t:.0f} s", flush=True)
+# image regions (x0, x1, y0, y1) that isolate the three kinds of material response
+REGIONS = {"metal sphere (Phong lobe)": (285, 515, 640, 880), "glass sphere (dielectric)": (640, 915, 665, 940),
+           "light and ceiling": (300, 860, 40, 170), "back wall (diffuse)": (210, 950, 190, 600), "red wall": (0, 190, 100, 900), "blue wall": (970, 1162, 100, 900)}
 for name, cam in (("default", p0), ("fitted", p)):
     img = render(cam, FINAL)
     print(f"{name}: {FINAL} spp  RMSE {np.sqrt(np.mean((img - ref) ** 2)):.3f}  RMSE(4x4 mean) {np.sqrt(np.mean((blur(img, 4) - ref4) ** 2)):.3f} "
           f" RMSE(8x8 mean) {np.sqrt(np.mean((blur(img, 8) - blur(ref, 8)) ** 2)):.3f}  channel means ours {np.round(img.mean(axis=(0, 1)), 2)} ref {np.round(ref.mean(axis=(0, 1)), 2)}", flush=True)
+    if name == "fitted":
+        for rn, (x0, x1, y0, y1) in REGIONS.items():
+            a, b = img[y0:y1, x0:x1], ref[y0:y1, x0:x1]
+            print(f"  {rn:28s} RMSE {np.sqrt(np.mean((a - b) ** 2)):.3f}  RMSE(8x8 mean) {np.sqrt(np.mean((blur(a, 8) - blur(b, 8)) ** 2)):.3f}  "
+                  f"channel means ours {np.round(a.mean(axis=(0, 1)), 2)} ref {np.round(b.mean(axis=(0, 1)), 2)}", flush=True)
     Image.fromarray(img.astype(np.uint8)).save(os.path.join(ROOT, "gpurun_out", f"scene01_{name}_{FINAL}.png"))
     Image.fromarray(np.clip(np.abs(img - ref).mean(axis=2) * 4, 0, 255).astype(np.uint8)).save(os.path.join(ROOT, "gpurun_out", f"scene01_{name}_{FINAL}_diff.png"))
 ctx.close()
