@@ -293,6 +293,9 @@ def main():
                                    f"RCCL all-reduce + resolve at the end)",
                        "triangles": int(ctx.n), "parallelism": f"frames{world}"},
             "mpaths_per_s": paths / dt / 1e6,
+            # the reference's only published figure for this path (report.md:96): another GPU, unnamed scene,
+            # a different unit than the metric -- listed for orientation, not as vs_baseline
+            "reference_published": {"mpaths_per_s": 14.0, "hardware": "NVIDIA GTX 1060", "image": "1k x 1k", "source": "report.md:96"},
             "rays_per_path": rays / paths,
             "traversal": {"node_visits_per_ray": visits_per_ray, "tri_tests_per_ray": tris_per_ray,
                           "bytes_per_ray": bytes_per_ray},
