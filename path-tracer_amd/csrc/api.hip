@@ -90,6 +90,7 @@ int pt_create(int device_ordinal, pt_context **out)
     pt_context *ctx = new pt_context();
     ctx->device = device_ordinal;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->samples_cap_bytes = (size_t)prop.totalGlobalMem / 8;
     int rc = set_device(ctx);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_cb, 1);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_bbox_enc, 16);

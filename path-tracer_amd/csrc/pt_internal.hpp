@@ -123,6 +123,7 @@ struct pt_context {
     uint32_t *d_pixel_work = nullptr; // W*H, iterations of the current launch
     float4 *d_samples = nullptr;      // [samples_frames][W*H] radiance samples of one launch
     uint32_t samples_frames = 0;
+    size_t samples_cap_bytes = 0;     // upper bound of the staging buffer: an eighth of the device's memory
     // wavefront trace: two path queues (48-byte records), hit records (16 bytes), queue lengths
     void *d_wf_queue[2] = {nullptr, nullptr};
     void *d_wf_hits = nullptr;
