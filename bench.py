@@ -174,9 +174,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a box with fewer GPUs than ranks: PTAMD_BENCH_DEVICE pins every rank to one device and
+    # PTAMD_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU); never used by the driver
+    if os.environ.get("PTAMD_BENCH_DEVICE"):
+        local_rank = int(os.environ["PTAMD_BENCH_DEVICE"])
+    backend = os.environ.get("PTAMD_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
