@@ -136,7 +136,10 @@ int pt_trace(pt_context *ctx, uint32_t framecount, uint32_t seed);
  * each pixel running its frames back to back; seeds[i] belongs to frame
  * first_frame+i (host pointer).  mode PT_ACCUM_LITERAL gives exactly the images
  * `count` pt_trace calls give; PT_ACCUM_LINEAR adds the linear samples into a
- * float RGBA sum (alpha counts samples) that pt_resolve turns into the images. */
+ * float RGBA sum (alpha counts samples) that pt_resolve turns into the images.
+ * Memory: the samples of a launch are staged on the device, 16 bytes per pixel and frame, in a
+ * buffer that grows to the largest launch seen and is capped at an eighth of the device's memory
+ * (at least 4 GiB); a call with more frames than fit is split into several launches. */
 #define PT_ACCUM_LITERAL 0
 #define PT_ACCUM_LINEAR  1
 int pt_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, const uint32_t *seeds, int mode);
