@@ -333,15 +333,18 @@ struct Tuning { int refill_t, leaf_t; int itr_limit; };    // itr_limit: a path 
 // nearly every refill round for the few lanes that start a path, here every lane does useful work.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_path_seeds(int W, unsigned npix, uint32_t count, const uint32_t *__restrict__ seeds,
-                                                    float4 *__restrict__ samples)
+                                                    float4 *__restrict__ samples, int frame_lanes_log2)
 {
-    const size_t total = (size_t)npix * count;
-    for (size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x; slot < total; slot += (size_t)gridDim.x * 256) {
-        const unsigned px = (unsigned)(slot / count), fl = (unsigned)(slot - (size_t)px * count);
+    // A workgroup covers 256 >> frame_lanes_log2 pixels; the lanes of a pixel stride over its frames, so a
+    // pixel's slots are written side by side and no index needs a division by `count`.
+    const unsigned fl0 = threadIdx.x & ((1u << frame_lanes_log2) - 1u), frame_lanes = 1u << frame_lanes_log2;
+    const unsigned px_per_block = 256u >> frame_lanes_log2;
+    for (unsigned px = blockIdx.x * px_per_block + (threadIdx.x >> frame_lanes_log2); px < npix; px += gridDim.x * px_per_block) {
         const unsigned y = px / (unsigned)W, x = px - y * (unsigned)W;
         // ray_tracing.hlsl:410: uint(launchIndex.x + launchIndex.y * viewportDims.x), in float
         const uint32_t pixel_id = (uint32_t)((float)x + (float)y * (float)W);
-        samples[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rand_init(pixel_id, seeds[fl])));
+        for (unsigned fl = fl0; fl < count; fl += frame_lanes)
+            samples[(size_t)px * count + fl] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rand_init(pixel_id, seeds[fl])));
     }
 }
 
@@ -1418,8 +1421,10 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             const bool ordered = !no_order && items < 32ull * lanes;
             if (!ordered) ctx->order_valid = false;
             PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
+            int frame_lanes_log2 = 0;                    // lanes per pixel: the largest power of two <= count, at most 256
+            while (frame_lanes_log2 < 8 && (2u << frame_lanes_log2) <= cnt) frame_lanes_log2++;
             hipLaunchKernelGGL(k_path_seeds, dim3((unsigned)ctx->num_cus * 16u), dim3(256), 0, ctx->stream, ctx->W, (unsigned)npix, cnt,
-                               seeds, ctx->d_samples);
+                               seeds, ctx->d_samples, frame_lanes_log2);
 #define PT_LAUNCH(C, L) do { \
             PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_persistent<C, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
             hipLaunchKernelGGL((k_trace_persistent<C, L>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
