@@ -26,6 +26,14 @@ __device__ __forceinline__ float dec_f(unsigned u)
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
+typedef float f4v __attribute__((ext_vector_type(4)));
+// streaming store of 16 bytes that nothing in this kernel reads again
+__device__ __forceinline__ void nt_store4(float4 *p, float a, float b, float c, float d)
+{
+    f4v v = {a, b, c, d};
+    __builtin_nontemporal_store(v, reinterpret_cast<f4v *>(p));
+}
+
 __device__ __forceinline__ float wave_min(float v)
 {
 #pragma unroll
@@ -74,8 +82,8 @@ __global__ __launch_bounds__(256) void k_bounds(const uint4 *__restrict__ prims1
         b.mn[0] = mn[0]; b.mn[1] = mn[1]; b.mn[2] = mn[2]; b.pad = 0.0f;
         b.mx[0] = mx[0]; b.mx[1] = mx[1]; b.mx[2] = mx[2]; b.index = (int32_t)(first + t);
         float4 *dst = reinterpret_cast<float4 *>(&boxes[first + t]);
-        dst[0] = make_float4(b.mn[0], b.mn[1], b.mn[2], 0.0f);
-        dst[1] = make_float4(b.mx[0], b.mx[1], b.mx[2], __int_as_float(b.index));
+        nt_store4(&dst[0], b.mn[0], b.mn[1], b.mn[2], 0.0f);
+        nt_store4(&dst[1], b.mx[0], b.mx[1], b.mx[2], __int_as_float(b.index));
     } else {
         const float inf = __uint_as_float(0x7f800000u);
 #pragma unroll
@@ -360,6 +368,8 @@ __device__ __forceinline__ int node_id(long long b, int k, int n)
 __device__ __forceinline__ void write_wide(WideNode *__restrict__ w, const float *L, const float *R, int left, int right)
 {
     float4 *dst = reinterpret_cast<float4 *>(w);
+    // ordinary stores: a workgroup's node ids are scattered (a left child is named by its last key), and
+    // streaming stores of partial lines made this kernel three times slower
     dst[0] = make_float4(L[0], L[1], L[2], L[3]);
     dst[1] = make_float4(L[4], L[5], R[0], R[1]);
     dst[2] = make_float4(R[2], R[3], R[4], R[5]);
