@@ -270,6 +270,21 @@ def test_deep_tree_needs_opt_in(gpu_ctx_factory):
     assert np.array_equal(_bits(ctx.output()), _bits(old))
 
 
+def test_4k_frames_bit_exact(gpu_ctx_factory, golden):
+    """3840x2160 (the largest image of the named configurations; pixel ids beyond 2^22, which the seed
+    of ray_tracing.hlsl:410 forms in float), scene02, frames 64 and 65 in one launch: every pixel equal."""
+    W, H = 3840, 2160
+    ctx = gpu_ctx_factory()
+    sc, gb, _ = _setup(ctx, golden["scene02"], W, H)
+    seeds = ptamd.frame_seeds(3, 64, 2)
+    ctx.trace_frames(64, seeds, ptamd.PT_ACCUM_LITERAL)
+    old = np.zeros((H, W, 4), np.float32)
+    for k in range(2):
+        old, outu, _, _ = orc.trace_frame(sc, gb, 64 + k, seeds[k], old)
+    assert np.array_equal(_bits(ctx.output()), _bits(old))
+    assert np.array_equal(ctx.display(), outu)
+
+
 @pytest.mark.parametrize("scene", ["scene01", "scene04"])
 def test_full_size_frames_bit_exact(gpu_ctx_factory, golden, scene):
     """1162x1008 (the benchmark size), frames 0 and 1, fixed seeds: every pixel equal to the oracle."""
