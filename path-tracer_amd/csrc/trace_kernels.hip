@@ -604,6 +604,8 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
             }
             if (COUNT) sched[8] += (unsigned long long)((long long)__builtin_readcyclecounter() - t_refill);
         }
+        // waves in the traversal loop issue ahead of waves in a (long, VALU-dense) refill round: 0.8 % per launch
+        __builtin_amdgcn_s_setprio(1);
         const long long t_trav = COUNT ? (long long)__builtin_readcyclecounter() : 0;
         // --------------------------------------------------------- traversal
         // One loop pass = EXPANSIONS node expansions, each followed by a pop attempt, with the loop control
@@ -698,6 +700,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
             }
             pop();
         }
+        __builtin_amdgcn_s_setprio(0);
         if (COUNT) sched[9] += (unsigned long long)((long long)__builtin_readcyclecounter() - t_trav);
     }
     flush_counters(cnt, counters, COUNT);
