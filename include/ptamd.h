@@ -103,6 +103,26 @@ int pt_download_sorted_primitives(pt_context *ctx, pt_PrimitiveRayCS *out /* n: 
  * a build (links from the closed form, boxes = unions of the child boxes: the refit's own values). */
 int pt_download_tree(pt_context *ctx, pt_TreeNode *out /* 2n: tree_uav */);
 
+/* Build that allocates nothing.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * allocate device memory -- code under HIP graph capture, tight loops that rebuild a small dynamic
+ * scene every frame, harnesses that forbid hipMalloc.  It runs the kernels of pt_build
+ * (PT_BUILD_TREE_ONLY form) over caller-owned inputs and outputs, all DEVICE pointers:
+ *   dev_prims  n PrimitiveRender records (16-byte aligned), read only;
+ *   dev_morton n uint64 codes in primitive order, or NULL;
+ *   dev_perm   n int32: sorted position -> primitive;
+ *   dev_tree   2n TreeNode records in the reference's layout (16-byte aligned): tree_uav.
+ * Every intermediate buffer (boxes, codes, sort ping-pong, digit counts, partial boxes, node
+ * records: about 108 bytes per primitive) lives in one static device array of 14 MiB that each GPU
+ * the library runs on holds until the process ends; hence the limit n <= PT_NOALLOC_MAX_PRIMS, beyond
+ * which the call fails with PT_ERR_UNSUPPORTED.  flags: 0 or PT_BUILD_KARRAS_LINKS.  The context's
+ * own scene, tree and images are not touched.  Work is enqueued on the context's stream; no
+ * hipMalloc / hipFree / synchronisation happens inside.  All calls on one GPU share the array (also
+ * from different contexts): calls that overlap in time on one GPU race and must be serialised by the
+ * caller (one stream, or events). */
+#define PT_NOALLOC_MAX_PRIMS 131072
+int pt_build_tree_noalloc(pt_context *ctx, const void *dev_prims, int n, unsigned flags,
+                          uint64_t *dev_morton, int32_t *dev_perm, pt_TreeNode *dev_tree);
+
 /* ---- images -----------------------------------------------------------------
  * replaces: RayTracer::resize (ray_tracer.cpp:188-261): (re)creates the
  * accumulation / display / G-buffer images and resets the frame counter. */

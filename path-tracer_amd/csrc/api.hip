@@ -92,6 +92,7 @@ int pt_create(int device_ordinal, pt_context **out)
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->samples_cap_bytes = (size_t)prop.totalGlobalMem / 8;
     int rc = set_device(ctx);
+    if (!rc) rc = ptk_scratch_init(ctx);      // this device's address of the static scratch array
     if (!rc) rc = dev_alloc(ctx, &ctx->d_cb, 1);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_bbox_enc, 16);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_root, 8);

@@ -654,79 +654,192 @@ int ptk_order_pixels(pt_context *ctx, int shift)
 // ---------------------------------------------------------------------------
 // host-side sequencing
 // ---------------------------------------------------------------------------
-int ptk_build(pt_context *ctx, unsigned flags)
+// Stages bounds .. refit over the buffers of `b`.  `ev` (PT_STAGE_COUNT + 1 events) receives the
+// stage boundaries up to the end of the refit, or is null.  Returns which of b.vals holds the
+// permutation in *sorted_buf.
+static int run_build(pt_context *ctx, const BuildBufs &b, const uint4 *prims16, int n, unsigned flags,
+                     hipEvent_t *ev, int *sorted_buf)
 {
-    const int n = ctx->n;
     hipStream_t st = ctx->stream;
     const int grid_n = (n + 255) / 256;
-    const uint4 *prims16 = reinterpret_cast<const uint4 *>(ctx->d_prims);
 
-    PT_HIP(ctx, hipEventRecord(ctx->ev[0], st));
-    hipLaunchKernelGGL(k_bounds, dim3(grid_n), dim3(256), 0, st, prims16, n, ctx->d_boxes, ctx->d_bbox_partial);
-    hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(1024), 0, st, ctx->d_bbox_partial, grid_n, ctx->d_bbox_enc);
-    PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_BOUNDS + 1], st));
+    if (ev) PT_HIP(ctx, hipEventRecord(ev[0], st));
+    hipLaunchKernelGGL(k_bounds, dim3(grid_n), dim3(256), 0, st, prims16, n, b.boxes, b.bbox_partial);
+    hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(1024), 0, st, b.bbox_partial, grid_n, b.bbox_enc);
+    if (ev) PT_HIP(ctx, hipEventRecord(ev[PT_STAGE_BOUNDS + 1], st));
 
     const bool full = (flags & PT_BUILD_MORTON_FULL) != 0;
     const float cells = full ? 2097151.0f : (float)PT_MORTON_CODE_LENGTH_EACH;
     // the reference's codes have 15 bits: 32-bit keys halve the sort's key traffic
-    if (full) hipLaunchKernelGGL(k_morton<uint64_t>, dim3(grid_n), dim3(256), 0, st, ctx->d_boxes, n, ctx->d_bbox_enc, cells, ctx->d_morton);
-    else      hipLaunchKernelGGL(k_morton<uint32_t>, dim3(grid_n), dim3(256), 0, st, ctx->d_boxes, n, ctx->d_bbox_enc, cells,
-                                 reinterpret_cast<uint32_t *>(ctx->d_morton));
-    ctx->morton_bits = full ? 64 : 32;
-    PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_MORTON + 1], st));
+    if (full) hipLaunchKernelGGL(k_morton<uint64_t>, dim3(grid_n), dim3(256), 0, st, b.boxes, n, b.bbox_enc, cells,
+                                 static_cast<uint64_t *>(b.morton));
+    else      hipLaunchKernelGGL(k_morton<uint32_t>, dim3(grid_n), dim3(256), 0, st, b.boxes, n, b.bbox_enc, cells,
+                                 static_cast<uint32_t *>(b.morton));
+    if (ev) PT_HIP(ctx, hipEventRecord(ev[PT_STAGE_MORTON + 1], st));
 
     // The reference quantises each axis to 0..21 (5 bits), so its codes occupy
     // 15 bits: two 8-bit passes sort them completely.  Full-resolution codes
     // have 63 bits: eight passes.
     const int passes = full ? 8 : 2;
     if (full) {
-        uint64_t *const kb[2] = {ctx->d_keys[0], ctx->d_keys[1]};
-        ctx->sorted_buf = radix_sort_passes<uint64_t>(st, ctx->d_morton, n, passes, kb, ctx->d_vals, ctx->d_block_hist, ctx->d_digit_total);
+        uint64_t *const kb[2] = {static_cast<uint64_t *>(b.keys[0]), static_cast<uint64_t *>(b.keys[1])};
+        *sorted_buf = radix_sort_passes<uint64_t>(st, static_cast<const uint64_t *>(b.morton), n, passes, kb, b.vals,
+                                                  b.block_hist, b.digit_total);
     } else {
-        uint32_t *const kb[2] = {reinterpret_cast<uint32_t *>(ctx->d_keys[0]), reinterpret_cast<uint32_t *>(ctx->d_keys[1])};
-        ctx->sorted_buf = radix_sort_passes<uint32_t>(st, reinterpret_cast<const uint32_t *>(ctx->d_morton), n, passes, kb, ctx->d_vals,
-                                                      ctx->d_block_hist, ctx->d_digit_total);
+        uint32_t *const kb[2] = {static_cast<uint32_t *>(b.keys[0]), static_cast<uint32_t *>(b.keys[1])};
+        *sorted_buf = radix_sort_passes<uint32_t>(st, static_cast<const uint32_t *>(b.morton), n, passes, kb, b.vals,
+                                                  b.block_hist, b.digit_total);
     }
-    ctx->sort_passes = passes;
-    PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_SORT + 1], st));
+    if (ev) PT_HIP(ctx, hipEventRecord(ev[PT_STAGE_SORT + 1], st));
 
     // The topology of the index-keyed tree is a closed form of n (see the refit kernels): the
     // refit writes child ids from it, and nothing else has to run for this stage.
-    PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_TOPOLOGY + 1], st));
+    if (ev) PT_HIP(ctx, hipEventRecord(ev[PT_STAGE_TOPOLOGY + 1], st));
 
-    const uint32_t *perm = ctx->d_vals[ctx->sorted_buf];
+    const uint32_t *perm = b.vals[*sorted_buf];
     const int nchunks = (int)(((long long)n + 1 + PT_REFIT_CHUNK - 1) / PT_REFIT_CHUNK);
     const int top = bit_length((unsigned)n);
     const bool tree_only = (flags & PT_BUILD_TREE_ONLY) != 0;
     if (tree_only)
-        hipLaunchKernelGGL(k_refit_low<false>, dim3(nchunks), dim3(PT_REFIT_CHUNK), 0, st, perm, ctx->d_boxes, prims16, n, ctx->d_wide,
-                           ctx->d_chunk, ctx->d_tri_sorted, ctx->d_shade);
+        hipLaunchKernelGGL(k_refit_low<false>, dim3(nchunks), dim3(PT_REFIT_CHUNK), 0, st, perm, b.boxes, prims16, n, b.wide,
+                           b.chunk, b.tri, b.shade);
     else
-        hipLaunchKernelGGL(k_refit_low<true>, dim3(nchunks), dim3(PT_REFIT_CHUNK), 0, st, perm, ctx->d_boxes, prims16, n, ctx->d_wide,
-                           ctx->d_chunk, ctx->d_tri_sorted, ctx->d_shade);
+        hipLaunchKernelGGL(k_refit_low<true>, dim3(nchunks), dim3(PT_REFIT_CHUNK), 0, st, perm, b.boxes, prims16, n, b.wide,
+                           b.chunk, b.tri, b.shade);
     // levels above the chunks: groups of 2048 units per launch (two launches reach 2^32 keys)
     {
-        const ChunkBox *in = ctx->d_chunk;
-        ChunkBox *out = ctx->d_chunk + nchunks;          // second half of the buffer, then back
+        const ChunkBox *in = b.chunk;
+        ChunkBox *out = b.chunk + nchunks;          // second half of the buffer, then back
         long long units = nchunks;
         for (int base = PT_REFIT_CHUNK_LOG2; base < top; base += PT_REFIT_GROUP_LOG2) {
             const long long groups = (units + PT_REFIT_GROUP - 1) / PT_REFIT_GROUP;
-            hipLaunchKernelGGL(k_refit_upper, dim3((unsigned)groups), dim3(1024), 0, st, base, top, n, in, units, ctx->d_wide, out);
+            hipLaunchKernelGGL(k_refit_upper, dim3((unsigned)groups), dim3(1024), 0, st, base, top, n, in, units, b.wide, out);
             in = out;
-            out = ctx->d_chunk;
+            out = b.chunk;
             units = groups;
         }
     }
-    PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_REFIT + 1], st));
-
-    // the per-leaf records of the trace kernels were written by the refit (unless PT_BUILD_TREE_ONLY); what
-    // is left is the root's own box
+    if (ev) PT_HIP(ctx, hipEventRecord(ev[PT_STAGE_REFIT + 1], st));
     PT_HIP(ctx, hipGetLastError());
-    if (int rc = ptk_root_box(ctx)) return rc;
-    ctx->trace_records = !tree_only;
-    PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_PACK + 1], st));
     return PT_OK;
 }
+
+int ptk_build(pt_context *ctx, unsigned flags)
+{
+    BuildBufs b;
+    b.boxes = ctx->d_boxes; b.bbox_partial = ctx->d_bbox_partial; b.bbox_enc = ctx->d_bbox_enc;
+    b.keys[0] = ctx->d_keys[0]; b.keys[1] = ctx->d_keys[1];
+    b.vals[0] = ctx->d_vals[0]; b.vals[1] = ctx->d_vals[1];
+    b.morton = ctx->d_morton; b.block_hist = ctx->d_block_hist; b.digit_total = ctx->d_digit_total;
+    b.wide = ctx->d_wide; b.chunk = ctx->d_chunk; b.shade = ctx->d_shade; b.tri = ctx->d_tri_sorted;
+    const bool full = (flags & PT_BUILD_MORTON_FULL) != 0;
+    if (int rc = run_build(ctx, b, reinterpret_cast<const uint4 *>(ctx->d_prims), ctx->n, flags, ctx->ev, &ctx->sorted_buf)) return rc;
+    ctx->morton_bits = full ? 64 : 32;
+    ctx->sort_passes = full ? 8 : 2;
+    // the per-leaf records of the trace kernels were written by the refit (unless PT_BUILD_TREE_ONLY); what
+    // is left is the root's own box
+    if (int rc = ptk_root_box(ctx)) return rc;
+    ctx->trace_records = (flags & PT_BUILD_TREE_ONLY) == 0;
+    PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_PACK + 1], ctx->stream));
+    return PT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Build without any allocation: every intermediate buffer of the build comes out of ONE static
+// device array, for callers that cannot call hipMalloc (code under HIP graph capture, tight
+// serving loops that rebuild a small scene every frame).  Each GPU the library runs on holds its
+// own copy of the array, at its own address, until the process ends; host code must never use the
+// array's NAME as an address (it is a host-side stand-in): the address is asked for once per
+// device by ptk_scratch_init, kept in the context, and handed to the kernels as an argument like
+// any other buffer.  All calls on one GPU share the array: calls that overlap on one GPU race.
+// ---------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char scratch[PT_NOALLOC_SCRATCH_BYTES];
+
+int ptk_scratch_init(pt_context *ctx)
+{
+    // the device of the context is current here (pt_create has just selected it)
+    void *p = nullptr;
+    PT_HIP(ctx, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) PT_FAIL(ctx, PT_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address");
+    ctx->d_scratch = static_cast<unsigned char *>(p);
+    return PT_OK;
+}
+
+namespace {
+// widens 32-bit codes into the reference's uint64 morton_code
+__global__ __launch_bounds__(256) void k_widen_codes(const uint32_t *__restrict__ in, int n, uint64_t *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+}  // namespace
+
+extern "C" int pt_build_tree_noalloc(pt_context *ctx, const void *dev_prims, int n, unsigned flags,
+                                     uint64_t *dev_morton, int32_t *dev_perm, pt_TreeNode *dev_tree)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!dev_prims || !dev_perm || !dev_tree || n < 1)
+        PT_FAIL(ctx, PT_ERR_INVALID, "pt_build_tree_noalloc: need primitives, n >= 1, dev_perm and dev_tree");
+    if (n > PT_NOALLOC_MAX_PRIMS)
+        PT_FAIL(ctx, PT_ERR_UNSUPPORTED, "pt_build_tree_noalloc: n exceeds PT_NOALLOC_MAX_PRIMS (" + std::to_string(PT_NOALLOC_MAX_PRIMS) +
+                "); use pt_build");
+    if (flags & ~PT_BUILD_KARRAS_LINKS) PT_FAIL(ctx, PT_ERR_INVALID, "pt_build_tree_noalloc: only PT_BUILD_KARRAS_LINKS is accepted");
+    if ((reinterpret_cast<uintptr_t>(dev_prims) & 15u) || (reinterpret_cast<uintptr_t>(dev_tree) & 15u) ||
+        (reinterpret_cast<uintptr_t>(dev_perm) & 3u) || (reinterpret_cast<uintptr_t>(dev_morton) & 7u))
+        PT_FAIL(ctx, PT_ERR_INVALID, "pt_build_tree_noalloc: dev_prims and dev_tree must be 16-byte aligned, dev_morton 8, dev_perm 4");
+    if (!ctx->d_scratch) PT_FAIL(ctx, PT_ERR_INVALID, "pt_build_tree_noalloc: no scratch address for this device");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+
+    // carve the scratch array (256-byte steps); sizes for the largest n are checked at compile time below
+    unsigned char *p = ctx->d_scratch;
+    auto take = [&](size_t bytes) { unsigned char *q = p; p += (bytes + 255) & ~(size_t)255; return q; };
+    const size_t nblocks = ((size_t)n + PT_SORT_TILE - 1) / PT_SORT_TILE;
+    const size_t nchunks = ((size_t)n + 1 + PT_REFIT_CHUNK - 1) / PT_REFIT_CHUNK;
+    BuildBufs b;
+    b.boxes = reinterpret_cast<BoxRec *>(take((size_t)n * sizeof(BoxRec)));
+    b.wide = reinterpret_cast<WideNode *>(take((size_t)n * sizeof(WideNode)));
+    b.morton = take((size_t)n * 4);
+    b.keys[0] = take((size_t)n * 4);
+    b.keys[1] = nullptr;                                     // the second (= last) pass writes no keys
+    b.vals[0] = reinterpret_cast<uint32_t *>(take((size_t)n * 4));
+    b.vals[1] = reinterpret_cast<uint32_t *>(dev_perm);      // two passes: the permutation ends in vals[1]
+    b.bbox_partial = reinterpret_cast<float *>(take(6 * (((size_t)n + 255) / 256) * sizeof(float)));
+    b.bbox_enc = reinterpret_cast<unsigned *>(take(64));
+    b.block_hist = reinterpret_cast<uint32_t *>(take(256 * nblocks * sizeof(uint32_t)));
+    b.digit_total = reinterpret_cast<uint32_t *>(take(8 * 256 * sizeof(uint32_t)));
+    b.chunk = reinterpret_cast<ChunkBox *>(take((nchunks + (nchunks + 2047) / 2048 + 1) * sizeof(ChunkBox)));
+    if ((size_t)(p - ctx->d_scratch) > (size_t)PT_NOALLOC_SCRATCH_BYTES)
+        PT_FAIL(ctx, PT_ERR_UNSUPPORTED, "pt_build_tree_noalloc: scratch array too small for n");
+    // Nothing in the scratch array has to start at zero: every word a kernel reads was written by an
+    // earlier kernel of this same call (boxes, partial boxes, codes, digit counts and totals, chunk
+    // boxes, node records), so the previous call's contents are never observed.
+    int sorted_buf = 0;
+    if (int rc = run_build(ctx, b, static_cast<const uint4 *>(dev_prims), n, PT_BUILD_TREE_ONLY, nullptr, &sorted_buf)) return rc;
+    if (sorted_buf != 1) PT_FAIL(ctx, PT_ERR_INVALID, "pt_build_tree_noalloc: unexpected sort buffer parity");
+    hipStream_t st = ctx->stream;
+    if (dev_morton)
+        hipLaunchKernelGGL(k_widen_codes, dim3((n + 255) / 256), dim3(256), 0, st, static_cast<const uint32_t *>(b.morton), n, dev_morton);
+    const int top = bit_length((unsigned)n);
+    hipLaunchKernelGGL(k_export_leaves, dim3((n + 255) / 256), dim3(256), 0, st, b.vals[1], b.boxes, n, dev_tree);
+    const long long nb1 = ((long long)n + 2) >> 1;
+    hipLaunchKernelGGL(k_export_nodes, dim3((unsigned)((nb1 + 255) / 256), (unsigned)top), dim3(256), 0, st, n, top, b.wide, dev_tree);
+    if (flags & PT_BUILD_KARRAS_LINKS)
+        hipLaunchKernelGGL(k_radix_tree, dim3((n + 255) / 256), dim3(256), 0, st, n, dev_tree);
+    PT_HIP(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+// bytes the carve-up above takes for the largest n (each piece rounded up to 256)
+namespace {
+constexpr size_t r256(size_t b) { return (b + 255) & ~(size_t)255; }
+constexpr size_t noalloc_need(size_t n)
+{
+    return r256(n * 32) + r256(n * 64) + 3 * r256(n * 4) + r256(6 * ((n + 255) / 256) * 4) + 256 +
+           r256(256 * ((n + PT_SORT_TILE - 1) / PT_SORT_TILE) * 4) + r256(8 * 256 * 4) +
+           r256((((n + 1 + 1023) / 1024) + ((n + 1 + 1023) / 1024 + 2047) / 2048 + 1) * sizeof(ChunkBox));
+}
+static_assert(noalloc_need(PT_NOALLOC_MAX_PRIMS) <= PT_NOALLOC_SCRATCH_BYTES, "scratch array too small for PT_NOALLOC_MAX_PRIMS");
+}  // namespace
 
 // Fills ctx->d_tree (2n nodes in the reference's layout).  With PT_BUILD_KARRAS_LINKS the links are
 // then rewritten by the search-based kernel that follows radix_build_cs.hlsl: the same values.

@@ -66,6 +66,38 @@ constexpr int PT_REFIT_CHUNK_LOG2 = 10;
 constexpr int PT_REFIT_CHUNK = 1 << PT_REFIT_CHUNK_LOG2;        // 1024 sorted keys per workgroup
 
 constexpr int PT_SEED_SLOTS = 4;
+// size of the library's static scratch array (pt_build_tree_noalloc): what PT_NOALLOC_MAX_PRIMS needs
+constexpr size_t PT_NOALLOC_SCRATCH_BYTES = (size_t)14 << 20;
+
+// Device buffers of one build.  pt_build fills this from the context's own allocations;
+// pt_build_tree_noalloc from the caller's outputs and the library's static scratch array.
+struct BuildBufs {
+    BoxRec *boxes = nullptr;            // n
+    float *bbox_partial = nullptr;      // 6 per 256 primitives
+    unsigned *bbox_enc = nullptr;       // 6 (+ padding)
+    void *keys[2] = {nullptr, nullptr}; // sort ping-pong, 4 or 8 bytes per key
+    uint32_t *vals[2] = {nullptr, nullptr};
+    void *morton = nullptr;             // n codes in primitive order, 4 or 8 bytes each
+    uint32_t *block_hist = nullptr;     // 256 per PT_SORT_TILE keys
+    uint32_t *digit_total = nullptr;    // 8 * 256
+    WideNode *wide = nullptr;           // n
+    ChunkBox *chunk = nullptr;          // per 1024 keys, plus the upper levels' groups
+    TriShade *shade = nullptr;          // n + 1 (unused with PT_BUILD_TREE_ONLY)
+    TriIsect *tri = nullptr;            // n + 1 (unused with PT_BUILD_TREE_ONLY)
+};
+
+// Tuning knobs for experiments, read from the environment ONCE, at pt_create (PTAMD_* variables;
+// unset = the defaults the measurements in this repository were taken with).
+struct Knobs {
+    int refill_t = 20, leaf_t = 12;     // PTAMD_REFILL_T, PTAMD_LEAF_T
+    int wf_refill_t = 16, wf_leaf_t = 12;
+    int samples_gib = 0;                // PTAMD_SAMPLES_GIB: cap of the sample staging buffer
+    int no_lds_tree = 0;                // PTAMD_NO_LDS_TREE: node records from global memory even when they fit
+    int max_threads = 0;                // PTAMD_MAX_THREADS: fewer waves per CU
+    int no_order = 0;                   // PTAMD_NO_ORDER: image order instead of most-expensive-first
+    int chunk = 0;                      // PTAMD_CHUNK: frames per work item
+    int print_sched = 0;                // PTAMD_PRINT_SCHED: scheduling statistics on stderr
+};
 
 struct pt_context {
     int device = 0;
@@ -149,6 +181,12 @@ struct pt_context {
     bool detailed = false;
     bool time_trace = false;          // record an event pair around the trace kernel of each launch
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;
+    std::vector<hipEvent_t> event_pool;   // timing events waiting for reuse
+    Knobs knobs;
+    int lds_attr[8] = {};             // dynamic-LDS limit already set per kernel variant (bytes)
+    int near_first = 0;               // PT_TRAVERSAL_*
+    unsigned char *d_scratch = nullptr;   // this device's copy of the library's static scratch array
+    void *rccl_comm = nullptr;        // communicator made by pt_comm_init_rank (owned)
     DevCounters *d_counters = nullptr;
 };
 
@@ -158,6 +196,7 @@ struct pt_context {
 
 // ---- launchers implemented in the kernel translation units ------------------
 int ptk_build(pt_context *ctx, unsigned flags);
+int ptk_scratch_init(pt_context *ctx);
 int ptk_root_box(pt_context *ctx);
 int ptk_order_pixels(pt_context *ctx, int shift);
 int ptk_export_sorted(pt_context *ctx, pt_PrimitiveRayCS *d_out);

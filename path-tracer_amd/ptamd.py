@@ -28,6 +28,7 @@ PT_BUILD_DEFAULT = 0
 PT_BUILD_MORTON_FULL = 1
 PT_BUILD_KARRAS_LINKS = 4
 PT_BUILD_TREE_ONLY = 8
+PT_NOALLOC_MAX_PRIMS = 131072
 PT_ACCUM_LITERAL = 0
 PT_ACCUM_LINEAR = 1
 PT_SCHEDULE_PERSISTENT = 0
@@ -38,7 +39,7 @@ STAGES = ("bounds", "morton", "sort", "topology", "refit", "pack")
 EXPORTS = (
     "pt_create", "pt_destroy", "pt_last_error", "pt_set_stream", "pt_synchronize", "pt_version",
     "pt_upload_primitives", "pt_upload_primitives_device", "pt_set_constants",
-    "pt_build", "pt_build_times",
+    "pt_build", "pt_build_times", "pt_build_tree_noalloc",
     "pt_download_scene_bound", "pt_download_morton", "pt_download_permutation",
     "pt_download_sorted_primitives", "pt_download_tree",
     "pt_resize", "pt_upload_gbuffer", "pt_download_gbuffer", "pt_primary_hits", "pt_albedo_bytes",
@@ -171,6 +172,12 @@ class Context:
 
     def build(self, flags=PT_BUILD_DEFAULT):
         self._ck(self.L.pt_build(self.h, C.c_uint(flags)))
+
+    def build_tree_noalloc(self, dev_prims, n, dev_morton, dev_perm, dev_tree, flags=0):
+        """Device pointers in, device pointers out; nothing is allocated (pt_build_tree_noalloc)."""
+        self._ck(self.L.pt_build_tree_noalloc(self.h, C.c_void_p(int(dev_prims)), C.c_int(n), C.c_uint(flags),
+                                              C.c_void_p(int(dev_morton) if dev_morton else None),
+                                              C.c_void_p(int(dev_perm)), C.c_void_p(int(dev_tree))))
 
     def build_times(self):
         ms = (C.c_float * len(STAGES))()
