@@ -46,14 +46,21 @@ typedef enum pt_status {
 int         pt_create(int device_ordinal, pt_context **out);
 void        pt_destroy(pt_context *ctx);
 const char *pt_last_error(const pt_context *ctx);     /* ctx may be NULL: last create error */
-/* hipStream_t as void*; NULL = the default stream */
+/* hipStream_t as void*; NULL = the default stream.  Work already enqueued on the previous stream is
+ * drained (the call blocks for it) before the switch, so nothing of this context is ever in flight on
+ * two streams; pending pt_get_trace_times entries are dropped. */
 int         pt_set_stream(pt_context *ctx, void *hip_stream);
 int         pt_synchronize(pt_context *ctx);
 const char *pt_version(void);
 
 /* ---- scene upload ---------------------------------------------------------
  * replaces: addSRV(sizeof(PrimitiveRender), n, renderer_primitives.data())
- * (ray_tracer.cpp:144-147).  Host or device memory, n >= 1. */
+ * (ray_tracer.cpp:144-147).  Host or device memory, n >= 1.
+ * Material ids: the constant buffer holds 16 materials (structs.hlsli).  pt_upload_primitives checks
+ * every `matid` and fails with PT_ERR_UNSUPPORTED outside 0..15.  Device-side inputs cannot be checked
+ * up front (pt_upload_primitives_device, the G-buffer's asint(normal.w) - 1): there an id outside
+ * 0..15 reads an all-zero material, as an out-of-range constant-buffer read does in Direct3D 11, and
+ * never memory beyond the table; a non-positive G-buffer material word is background. */
 int pt_upload_primitives(pt_context *ctx, const pt_PrimitiveRender *host_prims, int n);
 int pt_upload_primitives_device(pt_context *ctx, const void *dev_prims, int n);
 /* replaces: the per-frame Map/write of constant_buffers_[0] (CS.cpp:405-439).
@@ -152,6 +159,15 @@ void pt_albedo_bytes(const float kd[3], int srgb_quirk, uint8_t out_rgb[3]);
  *   out = pow(pow(old, 2.2) * f/(f+1) + sample/(f+1), 1/2.2),  f = framecount.
  * `seed` is g_random[0] of that frame. */
 int pt_trace(pt_context *ctx, uint32_t framecount, uint32_t seed);
+/* replaces: ONE Dispatch of the tile loop of RayTracer::trace (ray_tracer.cpp:302-332) with
+ * CB_RT.offset = {x0, y0, x1, y1}: the shader adds (x0, y0) to the thread id and returns when
+ * x > x1 or y > y1 (ray_tracing.hlsl:402-406), so the rectangle x0..x1 by y0..y1, bounds INCLUSIVE
+ * and clipped to the image, receives frame `framecount` (literal accumulate); every other pixel
+ * keeps its value (output and old are whole-image copies of each other).  The reference draws a new
+ * seed per tile; pass the same seed to every tile to get exactly the image of one pt_trace.  Sets
+ * the frame counter to framecount + 1, as the last tile of a frame does.  Always the persistent
+ * schedule. */
+int pt_trace_region(pt_context *ctx, uint32_t framecount, uint32_t seed, int x0, int y0, int x1, int y1);
 /* `count` consecutive frames first_frame .. first_frame+count-1 in ONE launch,
  * each pixel running its frames back to back; seeds[i] belongs to frame
  * first_frame+i (host pointer).  mode PT_ACCUM_LITERAL gives exactly the images
@@ -178,6 +194,23 @@ int pt_reset_accumulation(pt_context *ctx);            /* frame_count = 0, image
 int pt_linear_sum_device_ptr(pt_context *ctx, void **dev_ptr, size_t *bytes);
 int pt_resolve(pt_context *ctx);
 
+/* ---- multi-GPU merge ------------------------------------------------------------
+ * No counterpart in the reference (one GPU, ray_tracer.cpp:281-335).  One process per GPU; every
+ * rank traces its own frames in PT_ACCUM_LINEAR mode; pt_reduce_linear_sum then runs ONE in-place
+ * RCCL all-reduce (sum, float32, width*height*4 elements) of the linear sums on the context's
+ * stream, after which every rank holds the sums (and sample counts) of the whole job and
+ * pt_resolve gives the final image.  `nccl_comm` is an ncclComm_t of the caller (same device), or
+ * NULL to use the communicator made by pt_comm_init_rank.  librccl is loaded at the first of these
+ * calls; a process that already holds one (torch.distributed) shares it.
+ * pt_comm_unique_id: rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks
+ * by any means; pt_comm_init_rank (collective: every rank calls it) is ncclCommInitRank on the
+ * context's device; pt_comm_destroy releases it (pt_destroy does too). */
+typedef struct pt_comm_id { char bytes[128]; } pt_comm_id;
+int pt_comm_unique_id(pt_comm_id *out);                /* errors: pt_last_error(NULL) */
+int pt_comm_init_rank(pt_context *ctx, int n_ranks, int rank, const pt_comm_id *id);
+int pt_comm_destroy(pt_context *ctx);
+int pt_reduce_linear_sum(pt_context *ctx, void *nccl_comm);
+
 /* outputs: `output` RGBA32F (textures_[output_tex_index]) and `output_u` RGBA8
  * (textures_[output_unorm_tex_index], what CS.cpp:503,511 reads) */
 int pt_download_output(pt_context *ctx, float *rgba32f);
@@ -188,10 +221,24 @@ int pt_output_device_ptr(pt_context *ctx, void **dev_rgba32f, void **dev_rgba8);
 /* traversal stack depth.  The reference keeps 15 entries per path and silently drops subtrees
  * beyond them (ray_tracing.hlsl:235-238), which happens for trees deeper than 13 levels
  * (n > 16383).  This library never drops (it keeps one pending child per tree level), so for
- * such trees its images differ from the reference's: 15 makes the trace calls refuse those
- * trees, 32 states the opt-in to the non-dropping result (NON-PARITY for deep trees), 0
- * (default) traces any tree without asking.  Allowed: 0, 15, 32. */
+ * such trees its images differ from the reference's (NON-PARITY; they equal the reference
+ * algorithm run with a stack that never overflows).
+ *   0  (default) and 32: trace any tree with the non-dropping traversal;
+ *   15: strict-parity guard -- the trace calls refuse trees deeper than the reference's stack
+ *       handles, so every image a context in this mode produces is one the reference produces.
+ * Allowed: 0, 15, 32. */
 int pt_set_stack_size(pt_context *ctx, int entries);
+
+/* order in which the two children of a node are visited.  PT_TRAVERSAL_REFERENCE (default): left
+ * child first, always (ray_tracing.hlsl:228-233 pushes right, then left).  PT_TRAVERSAL_NEAR_FIRST:
+ * when both children pass their box test, the one the ray enters first (ties: left) -- far fewer node
+ * visits on large scenes, where the reference's order walks the whole ray before it meets the
+ * nearest hit.  NON-PARITY: the closest hit is the same triangle except where two triangles are hit
+ * at bit-equal or rounding-close distances (the reference keeps the first in ITS visit order);
+ * node-visit counters differ.  Persistent schedule only. */
+#define PT_TRAVERSAL_REFERENCE  0
+#define PT_TRAVERSAL_NEAR_FIRST 1
+int pt_set_traversal_order(pt_context *ctx, int order);
 
 /* longest path, in rays after the G-buffer hit.  The reference ends a path when its counter `itr`
  * (1 at the first bounce, +1 per hit) reaches MAX_ITR * 3 = 15, i.e. after 14 intersect() calls
@@ -224,6 +271,14 @@ typedef struct pt_counters {
 int pt_set_detailed_counters(pt_context *ctx, int enabled);
 int pt_get_counters(pt_context *ctx, pt_counters *out);   /* synchronises */
 int pt_reset_counters(pt_context *ctx);
+
+/* Environment variables read ONCE, by pt_create, for experiments (unset = defaults; none changes a
+ * result): PTAMD_REFILL_T / PTAMD_LEAF_T (wave-vote thresholds of the persistent kernel, 20 / 12),
+ * PTAMD_WF_REFILL_T / PTAMD_WF_LEAF_T (same, wavefront schedule), PTAMD_SAMPLES_GIB (cap of the
+ * sample staging buffer), PTAMD_NO_LDS_TREE=1 (node records from global memory even when they fit
+ * in LDS), PTAMD_MAX_THREADS (fewer waves per CU), PTAMD_NO_ORDER=1 (image order instead of
+ * most-expensive-first), PTAMD_CHUNK (frames per work item), PTAMD_PRINT_SCHED=1 (scheduling
+ * statistics of the instrumented kernel on stderr at pt_get_counters). */
 
 /* device-side duration of the trace kernel of every launch since timing was enabled (or since the
  * last pt_get_trace_times): HIP events on the context's stream around the persistent trace kernel

@@ -448,8 +448,17 @@ static int intersect(const orc_scene *sc, const orc_ray *ray, int *primitive_ind
                     }
                 }
             } else {
-                stack[--stack_top] = sc->tree[current].right;
-                stack[--stack_top] = sc->tree[current].left;
+                int first = sc->tree[current].left, second = sc->tree[current].right;
+                if (sc->near_first) {
+                    /* NON-PARITY option: when both children pass their box test now, the one the ray
+                     * enters first is visited first (ties: left, the reference's order) */
+                    float tl, tr;
+                    int hl = intersection_bound(ray, &sc->tree[first].bound, *current_t, &tl);
+                    int hr = intersection_bound(ray, &sc->tree[second].bound, *current_t, &tr);
+                    if (hl && hr && tr < tl) { int tmp = first; first = second; second = tmp; }
+                }
+                stack[--stack_top] = second;
+                stack[--stack_top] = first;
                 if (stack_top < 0) return intersected;
             }
         }
@@ -475,12 +484,20 @@ int orc_intersect_one(const orc_scene *s, const float origin[3], const float dir
 /* shading                                                                 */
 /* ======================================================================= */
 
+/* mats[id] of the constant buffer.  An index outside the 16 entries reads zeros, as an out-of-range
+ * constant-buffer read does in Direct3D 11 (the reference declares `Material mats[16]`, structs.hlsli). */
+static const pt_Material *material_of(const orc_scene *sc, int id)
+{
+    static const pt_Material zero_material;
+    return ((unsigned)id < (unsigned)PT_MAX_MATERIALS) ? &sc->cb->mats[id] : &zero_material;
+}
+
 /* ray_tracing.hlsl:249-346 */
 static int get_bounce(const orc_scene *sc, uint32_t framecount, pt_f3 view_dir, pt_f3 normal, int id,
                       pt_f3 *multi, pt_f3 *direction, uint32_t *seed)
 {
     *direction = pt_mk3(0, 0, 0);
-    const pt_Material *mat = &sc->cb->mats[id];
+    const pt_Material *mat = material_of(sc, id);
     float rand_mat = orc_rand_next(seed);
     float base = mat->tr + mat->ks.v[0] + mat->kd.v[0];
     if (mat->ke > 0) {
@@ -576,9 +593,9 @@ static pt_f3 second_tracing(const orc_scene *sc, uint32_t framecount,
     this_ray.t_max = 10000;
     pt_f3 multi = diffuse;
     int matid = (int)pt_f2u(normal_px[3]);               /* asint(normal.w) */
-    if (matid == 0) return zero;
+    if (matid <= 0) return zero;                         /* 0 = background; negative words are treated alike */
     matid -= 1;
-    if (sc->cb->mats[matid].ns > 1) multi = pt_mk3(1, 1, 1);
+    if (material_of(sc, matid)->ns > 1) multi = pt_mk3(1, 1, 1);
     pt_f3 direction;
     pt_f3 g_pos = ld3(&sc->cb->pos);
     if (!get_bounce(sc, framecount, pt_normalize3(pt_sub3(hitPos, g_pos)), pt_normalize3(normal), matid,
@@ -748,9 +765,11 @@ void orc_primary(const orc_scene *s, const orc_camera *cam, int W, int H,
             pt_f3 nn = pt_normalize3(pt_add3(pt_add3(pt_scale3(nA, bary.z), pt_scale3(nB, bary.x)), pt_scale3(nC, bary.y)));
             pt_f3 pp = pt_add3(pt_add3(pt_scale3(pA, bary.z), pt_scale3(pB, bary.x)), pt_scale3(pC, bary.y));
             int matid = pr->matid;
-            diffuse_rgba8[4 * p + 0] = albedo8[4 * matid + 0];
-            diffuse_rgba8[4 * p + 1] = albedo8[4 * matid + 1];
-            diffuse_rgba8[4 * p + 2] = albedo8[4 * matid + 2];
+            if ((unsigned)matid < (unsigned)PT_MAX_MATERIALS) {      /* a 16-entry table; other ids: black */
+                diffuse_rgba8[4 * p + 0] = albedo8[4 * matid + 0];
+                diffuse_rgba8[4 * p + 1] = albedo8[4 * matid + 1];
+                diffuse_rgba8[4 * p + 2] = albedo8[4 * matid + 2];
+            }
             diffuse_rgba8[4 * p + 3] = 255;
             normal_matid[4 * p + 0] = nn.x; normal_matid[4 * p + 1] = nn.y; normal_matid[4 * p + 2] = nn.z;
             normal_matid[4 * p + 3] = pt_u2f((uint32_t)(matid + 1));

@@ -74,6 +74,7 @@ typedef struct orc_scene {
     const pt_CB_Radix *cb;
     int stack_size;                     /* 15 = reference */
     int max_segments;                   /* rays per path at most; 0 = reference (14: itr reaches MAX_ITR * 3) */
+    int near_first;                     /* 0 = reference (left child first); 1 = NON-PARITY nearer child first */
 } orc_scene;
 
 typedef struct orc_counters {

@@ -40,7 +40,7 @@ class Camera(C.Structure):
 
 class Scene(C.Structure):
     _fields_ = [("n", C.c_int), ("prims", C.c_void_p), ("tree", C.c_void_p), ("cb", C.c_void_p),
-                ("stack_size", C.c_int), ("max_segments", C.c_int)]
+                ("stack_size", C.c_int), ("max_segments", C.c_int), ("near_first", C.c_int)]
 
 
 class Counters(C.Structure):
@@ -124,6 +124,35 @@ def build(prims):
     return {"rays": rays, "bb": bb, "sorted_rays": srt, "sorted_cs": cs, "tree": tree}
 
 
+def build_full_codes(prims):
+    """NON-PARITY build of PT_BUILD_MORTON_FULL: the reference's code arithmetic with 2^21 - 1 cells per axis
+    (float32, strict IEEE) instead of its 21, stable order, then the reference's index-keyed tree and refit."""
+    L = lib()
+    n = len(prims)
+    prims = np.ascontiguousarray(prims, dtype=PRIM_RENDER)
+    rays = np.zeros(n, dtype=PRIM_RAY)
+    L.orc_bounds(_p(prims), C.c_int(n), _p(rays))
+    bb = np.zeros(1, dtype=BOUND)
+    L.orc_scene_bound(_p(rays), C.c_int(n), _p(bb))
+    f = np.float32
+    mn, mx = rays["bound"]["min"], rays["bound"]["max"]
+    mid = ((mn + mx).astype(f) / f(2)).astype(f)
+    q = ((((mid - bb["min"][0]).astype(f) / (bb["max"][0] - bb["min"][0]).astype(f)).astype(f)) * f(2097151.0)).astype(f)
+    q = np.where(np.isnan(q), f(0), q).astype(np.uint64)
+    code = np.zeros(n, dtype=np.uint64)
+    for bit in range(21):
+        for axis, sh in ((0, 2), (1, 1), (2, 0)):
+            code |= ((q[:, axis] >> np.uint64(bit)) & np.uint64(1)) << np.uint64(3 * bit + sh)
+    rays["morton_code"] = code
+    srt = rays[np.argsort(code, kind="stable")]
+    cs = np.zeros(n, dtype=PRIM_RAY_CS)
+    L.orc_strip(_p(srt), C.c_int(n), _p(cs))
+    tree = np.zeros(2 * n + 1, dtype=TREENODE)
+    L.orc_radix_tree(C.c_int(n), _p(tree))
+    L.orc_refit(C.c_int(n), _p(cs), _p(tree))
+    return {"rays": rays, "bb": bb, "sorted_rays": srt, "sorted_cs": cs, "tree": tree}
+
+
 def radix_tree(n, literal=False):
     tree = np.zeros(2 * n + 1, dtype=TREENODE)
     (lib().orc_radix_tree_literal if literal else lib().orc_radix_tree)(C.c_int(n), _p(tree))
@@ -151,13 +180,14 @@ def albedo_table(cb, srgb_quirk=True, kd_override=None):
 class OracleScene:
     """Holds numpy buffers alive and exposes the C scene struct."""
 
-    def __init__(self, prims, tree, cb, stack_size=15, max_segments=0):
+    def __init__(self, prims, tree, cb, stack_size=15, max_segments=0, near_first=False):
         self.prims = np.ascontiguousarray(prims, dtype=PRIM_RENDER)
         self.tree = np.ascontiguousarray(tree, dtype=TREENODE)
         self.cb = np.ascontiguousarray(cb, dtype=CB_RADIX)
         self.n = len(self.prims)
         assert len(self.tree) == 2 * self.n + 1
-        self.c = Scene(self.n, self.prims.ctypes.data, self.tree.ctypes.data, self.cb.ctypes.data, stack_size, max_segments)
+        self.c = Scene(self.n, self.prims.ctypes.data, self.tree.ctypes.data, self.cb.ctypes.data, stack_size, max_segments,
+                       1 if near_first else 0)
 
 
 def primary(scene, cam, W, H, albedo8, threads=None):

@@ -7,8 +7,30 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <dlfcn.h>
 
 static std::string g_create_error;
+
+static int env_int(const char *name, int fallback)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? atoi(e) : fallback;
+}
+
+// PTAMD_* experiment knobs: read here, once per context, never on the launch path
+static void read_knobs(Knobs &k)
+{
+    k.refill_t = env_int("PTAMD_REFILL_T", k.refill_t);
+    k.leaf_t = env_int("PTAMD_LEAF_T", k.leaf_t);
+    k.wf_refill_t = env_int("PTAMD_WF_REFILL_T", k.wf_refill_t);
+    k.wf_leaf_t = env_int("PTAMD_WF_LEAF_T", k.wf_leaf_t);
+    k.samples_gib = env_int("PTAMD_SAMPLES_GIB", 0);
+    k.no_lds_tree = env_int("PTAMD_NO_LDS_TREE", 0);
+    k.max_threads = env_int("PTAMD_MAX_THREADS", 0);
+    k.no_order = env_int("PTAMD_NO_ORDER", 0);
+    k.chunk = env_int("PTAMD_CHUNK", 0);
+    k.print_sched = env_int("PTAMD_PRINT_SCHED", 0);
+}
 
 static int bit_length_u(unsigned v) { return v ? 32 - __builtin_clz(v) : 0; }
 
@@ -91,9 +113,17 @@ int pt_create(int device_ordinal, pt_context **out)
     ctx->device = device_ordinal;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->samples_cap_bytes = (size_t)prop.totalGlobalMem / 8;
+    read_knobs(ctx->knobs);
     int rc = set_device(ctx);
     if (!rc) rc = ptk_scratch_init(ctx);      // this device's address of the static scratch array
-    if (!rc) rc = dev_alloc(ctx, &ctx->d_cb, 1);
+    if (!rc) {
+        // the constants, followed by one all-zero material for ids outside 0..15
+        void *p = nullptr;
+        hipError_t e2 = hipMalloc(&p, sizeof(pt_CB_Radix) + sizeof(pt_Material));
+        if (e2 == hipSuccess) e2 = hipMemset(p, 0, sizeof(pt_CB_Radix) + sizeof(pt_Material));
+        if (e2 != hipSuccess) { ctx->err = std::string("constants: ") + hipGetErrorString(e2); rc = PT_ERR_HIP; }
+        ctx->d_cb = static_cast<pt_CB_Radix *>(p);
+    }
     if (!rc) rc = dev_alloc(ctx, &ctx->d_bbox_enc, 16);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_root, 8);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_digit_total, 8 * 256);
@@ -117,6 +147,8 @@ void pt_destroy(pt_context *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &e : ctx->trace_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->rccl_comm) (void)pt_comm_destroy(ctx);
     for (int k = 0; k < PT_SEED_SLOTS; k++) {
         if (ctx->h_seeds[k]) (void)hipHostFree(ctx->h_seeds[k]);
         if (ctx->seed_ev[k]) (void)hipEventDestroy(ctx->seed_ev[k]);
@@ -132,10 +164,24 @@ void pt_destroy(pt_context *ctx)
 
 const char *pt_last_error(const pt_context *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+static void drop_trace_events(pt_context *ctx)
+{   // the events go back to the pool: they are recorded again by later launches
+    for (auto &e : ctx->trace_events) { ctx->event_pool.push_back(e.first); ctx->event_pool.push_back(e.second); }
+    ctx->trace_events.clear();
+}
+
 int pt_set_stream(pt_context *ctx, void *hip_stream)
 {
     if (!ctx) return PT_ERR_INVALID;
-    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    hipStream_t next = reinterpret_cast<hipStream_t>(hip_stream);
+    if (next == ctx->stream) return PT_OK;
+    if (int rc = set_device(ctx)) return rc;
+    // Work already queued on the old stream (image clears, constant and seed copies, a build, event
+    // records) is not ordered with the new stream: drain it before switching.
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < PT_SEED_SLOTS; k++) ctx->seed_ev_used[k] = false;
+    drop_trace_events(ctx);          // an event pair must not span two streams
+    ctx->stream = next;
     return PT_OK;
 }
 
@@ -163,6 +209,11 @@ int pt_upload_primitives(pt_context *ctx, const pt_PrimitiveRender *host_prims, 
     if (!ctx) return PT_ERR_INVALID;
     if (!host_prims || n < 1) PT_FAIL(ctx, PT_ERR_INVALID, "pt_upload_primitives: need n >= 1 primitives");
     if (n >= (1 << 30)) PT_FAIL(ctx, PT_ERR_UNSUPPORTED, "pt_upload_primitives: n must be below 2^30");
+    // the constant buffer holds 16 materials (structs.hlsli: `Material mats[16]`)
+    for (int i = 0; i < n; i++)
+        if ((unsigned)host_prims[i].matid >= (unsigned)PT_MAX_MATERIALS)
+            PT_FAIL(ctx, PT_ERR_UNSUPPORTED, "pt_upload_primitives: primitive " + std::to_string(i) + " has material id " +
+                    std::to_string(host_prims[i].matid) + ", outside 0.." + std::to_string(PT_MAX_MATERIALS - 1));
     if (int rc = set_device(ctx)) return rc;
     void *d = nullptr;
     PT_HIP(ctx, hipMalloc(&d, (size_t)n * sizeof(pt_PrimitiveRender)));
@@ -466,19 +517,20 @@ static int check_trace_ready(pt_context *ctx, const char *who)
     if (ctx->cb.node_count != ctx->n) PT_FAIL(ctx, PT_ERR_INVALID, std::string(who) + ": CB_Radix.node_count differs from the primitive count");
     if (!ctx->W) PT_FAIL(ctx, PT_ERR_INVALID, std::string(who) + ": call pt_resize first");
     if (!ctx->have_gbuffer) PT_FAIL(ctx, PT_ERR_INVALID, std::string(who) + ": no G-buffer (pt_upload_gbuffer / pt_primary_hits)");
-    // The reference's 15-entry stack silently drops subtrees of trees deeper than
-    // 13 levels; this library never drops, so such scenes need the explicit opt-in.
+    // The reference's 15-entry stack silently drops subtrees of trees deeper than 13 levels; this
+    // library never drops.  stack_entries 15 is the strict-parity guard (deep trees are refused); 0, the
+    // default, and 32 trace any tree with the non-dropping traversal.
     if (ctx->stack_entries == 15 && bit_length_u((unsigned)ctx->n) > 14)
         PT_FAIL(ctx, PT_ERR_UNSUPPORTED, std::string(who) + ": tree deeper than the 15-entry reference stack; pt_set_stack_size(ctx, 32)");
     return PT_OK;
 }
 
-int pt_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, const uint32_t *seeds, int mode)
+static int trace_frames(pt_context *ctx, const char *who, uint32_t first_frame, uint32_t count, const uint32_t *seeds, int mode,
+                        const int *region)
 {
-    if (!ctx) return PT_ERR_INVALID;
-    if (int rc = check_trace_ready(ctx, "pt_trace_frames")) return rc;
-    if (!seeds || count < 1) PT_FAIL(ctx, PT_ERR_INVALID, "pt_trace_frames: need count >= 1 seeds");
-    if (mode != PT_ACCUM_LITERAL && mode != PT_ACCUM_LINEAR) PT_FAIL(ctx, PT_ERR_INVALID, "pt_trace_frames: bad mode");
+    if (int rc = check_trace_ready(ctx, who)) return rc;
+    if (!seeds || count < 1) PT_FAIL(ctx, PT_ERR_INVALID, std::string(who) + ": need count >= 1 seeds");
+    if (mode != PT_ACCUM_LITERAL && mode != PT_ACCUM_LINEAR) PT_FAIL(ctx, PT_ERR_INVALID, std::string(who) + ": bad mode");
     if (int rc = set_device(ctx)) return rc;
     if (ctx->seeds_cap < count) {
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -502,9 +554,29 @@ int pt_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, const
     PT_HIP(ctx, hipMemcpyAsync(ctx->d_seeds, ctx->h_seeds[slot], (size_t)count * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     PT_HIP(ctx, hipEventRecord(ctx->seed_ev[slot], ctx->stream));
     ctx->seed_ev_used[slot] = true;
-    if (int rc = ptk_trace_frames(ctx, first_frame, count, mode)) return rc;
+    if (int rc = ptk_trace_frames(ctx, first_frame, count, mode, region)) return rc;
     ctx->frame_count = first_frame + count;
     return PT_OK;
+}
+
+int pt_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, const uint32_t *seeds, int mode)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    return trace_frames(ctx, "pt_trace_frames", first_frame, count, seeds, mode, nullptr);
+}
+
+int pt_trace_region(pt_context *ctx, uint32_t framecount, uint32_t seed, int x0, int y0, int x1, int y1)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->W) PT_FAIL(ctx, PT_ERR_INVALID, "pt_trace_region: call pt_resize first");
+    if (x0 < 0 || y0 < 0) PT_FAIL(ctx, PT_ERR_INVALID, "pt_trace_region: negative offset");
+    // the shader's guard keeps x <= x1 and y <= y1 (ray_tracing.hlsl:405); texels outside the image do not exist
+    int region[4] = {x0, y0, x1 < ctx->W - 1 ? x1 : ctx->W - 1, y1 < ctx->H - 1 ? y1 : ctx->H - 1};
+    if (region[2] < region[0] || region[3] < region[1]) {      // nothing to trace: the dispatch would be empty
+        ctx->frame_count = framecount + 1;
+        return PT_OK;
+    }
+    return trace_frames(ctx, "pt_trace_region", framecount, 1, &seed, PT_ACCUM_LITERAL, region);
 }
 
 int pt_trace(pt_context *ctx, uint32_t framecount, uint32_t seed)
@@ -578,6 +650,15 @@ int pt_set_max_segments(pt_context *ctx, int segments)
     return PT_OK;
 }
 
+int pt_set_traversal_order(pt_context *ctx, int order)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (order != PT_TRAVERSAL_REFERENCE && order != PT_TRAVERSAL_NEAR_FIRST)
+        PT_FAIL(ctx, PT_ERR_INVALID, "pt_set_traversal_order: PT_TRAVERSAL_REFERENCE or PT_TRAVERSAL_NEAR_FIRST");
+    ctx->near_first = order;
+    return PT_OK;
+}
+
 int pt_set_trace_schedule(pt_context *ctx, int schedule)
 {
     if (!ctx) return PT_ERR_INVALID;
@@ -585,12 +666,6 @@ int pt_set_trace_schedule(pt_context *ctx, int schedule)
         PT_FAIL(ctx, PT_ERR_INVALID, "pt_set_trace_schedule: PT_SCHEDULE_PERSISTENT or PT_SCHEDULE_WAVEFRONT");
     ctx->schedule = schedule;
     return PT_OK;
-}
-
-static void drop_trace_events(pt_context *ctx)
-{
-    for (auto &e : ctx->trace_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    ctx->trace_events.clear();
 }
 
 int pt_set_trace_timing(pt_context *ctx, int enabled)
@@ -630,7 +705,7 @@ int pt_get_counters(pt_context *ctx, pt_counters *out)
     if (int rc = d2h(ctx, &h, ctx->d_counters, sizeof(h))) return rc;
     out->paths = h.paths; out->rays = h.rays; out->node_visits = h.node_visits;
     out->box_tests = h.box_tests; out->tri_tests = h.tri_tests;
-    if (getenv("PTAMD_PRINT_SCHED"))
+    if (ctx->knobs.print_sched)
         fprintf(stderr, "sched: iters %llu int_lanes %llu leaf_rounds %llu leaf_lanes %llu at_leaf_wait %llu refills %llu idle_wait %llu no_pixel %llu refill_ticks %llu trav_ticks %llu\n",
                 h.sched[0], h.sched[1], h.sched[2], h.sched[3], h.sched[4], h.sched[5], h.sched[6], h.sched[7], h.sched[8], h.sched[9]);
     return PT_OK;
@@ -641,6 +716,94 @@ int pt_reset_counters(pt_context *ctx)
     if (!ctx) return PT_ERR_INVALID;
     if (int rc = set_device(ctx)) return rc;
     PT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(DevCounters), ctx->stream));
+    return PT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Multi-GPU merge of the linear sums: RCCL, bound at first use (a single-GPU process never loads it).
+// Only the five entry points below are needed; their prototypes are the public ones of rccl.h.
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *id) = nullptr;                                   // ncclGetUniqueId(ncclUniqueId *)
+    int (*CommInitRank)(void **comm, int nranks, pt_comm_id id, int rank) = nullptr;   // ncclUniqueId is 128 bytes, by value
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*AllReduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t st) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+RcclApi g_rccl;
+
+bool rccl_load()
+{
+    if (g_rccl.AllReduce) return true;
+    // the soname first: a process that already holds an RCCL (torch.distributed) gets that same copy
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) { g_rccl.err = std::string("cannot load librccl: ") + dlerror(); return false; }
+    g_rccl.lib = h;
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    auto ar = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.GetErrorString || !ar) {
+        g_rccl.err = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce";
+        return false;
+    }
+    g_rccl.AllReduce = ar;
+    return true;
+}
+constexpr int kNcclFloat32 = 7, kNcclSum = 0;       // ncclFloat32, ncclSum of rccl.h
+}  // namespace
+
+int pt_comm_unique_id(pt_comm_id *out)
+{
+    if (!out) return PT_ERR_INVALID;
+    if (!rccl_load()) { g_create_error = g_rccl.err; return PT_ERR_UNSUPPORTED; }
+    const int r = g_rccl.GetUniqueId(out);
+    if (r != 0) { g_create_error = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r); return PT_ERR_HIP; }
+    return PT_OK;
+}
+
+int pt_comm_init_rank(pt_context *ctx, int n_ranks, int rank, const pt_comm_id *id)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks) PT_FAIL(ctx, PT_ERR_INVALID, "pt_comm_init_rank: bad rank / size / id");
+    if (ctx->rccl_comm) PT_FAIL(ctx, PT_ERR_INVALID, "pt_comm_init_rank: the context already has a communicator");
+    if (!rccl_load()) PT_FAIL(ctx, PT_ERR_UNSUPPORTED, g_rccl.err);
+    if (int rc = set_device(ctx)) return rc;
+    void *comm = nullptr;
+    const int r = g_rccl.CommInitRank(&comm, n_ranks, *id, rank);
+    if (r != 0) PT_FAIL(ctx, PT_ERR_HIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+    ctx->rccl_comm = comm;
+    return PT_OK;
+}
+
+int pt_comm_destroy(pt_context *ctx)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->rccl_comm) return PT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    const int r = g_rccl.CommDestroy(ctx->rccl_comm);
+    ctx->rccl_comm = nullptr;
+    if (r != 0) PT_FAIL(ctx, PT_ERR_HIP, std::string("ncclCommDestroy: ") + g_rccl.GetErrorString(r));
+    return PT_OK;
+}
+
+int pt_reduce_linear_sum(pt_context *ctx, void *nccl_comm)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->W) PT_FAIL(ctx, PT_ERR_INVALID, "pt_reduce_linear_sum: call pt_resize first");
+    void *comm = nccl_comm ? nccl_comm : ctx->rccl_comm;
+    if (!comm) PT_FAIL(ctx, PT_ERR_INVALID, "pt_reduce_linear_sum: no communicator (pass one, or call pt_comm_init_rank)");
+    if (!rccl_load()) PT_FAIL(ctx, PT_ERR_UNSUPPORTED, g_rccl.err);
+    if (int rc = set_device(ctx)) return rc;
+    // one in-place all-reduce of W*H float RGBA sums (alpha = sample count) on the context's stream
+    const int r = g_rccl.AllReduce(ctx->d_linear, ctx->d_linear, (size_t)ctx->W * ctx->H * 4, kNcclFloat32, kNcclSum, comm, ctx->stream);
+    if (r != 0) PT_FAIL(ctx, PT_ERR_HIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
     return PT_OK;
 }
 

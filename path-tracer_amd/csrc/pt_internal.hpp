@@ -110,7 +110,7 @@ struct pt_context {
     bool prims_owned = false;
     pt_CB_Radix cb{};
     bool have_cb = false;
-    pt_CB_Radix *d_cb = nullptr;
+    pt_CB_Radix *d_cb = nullptr;      // followed on the device by one all-zero pt_Material (ids outside 0..15)
 
     // build products
     bool built = false;
@@ -183,7 +183,7 @@ struct pt_context {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;
     std::vector<hipEvent_t> event_pool;   // timing events waiting for reuse
     Knobs knobs;
-    int lds_attr[8] = {};             // dynamic-LDS limit already set per kernel variant (bytes)
+    int lds_attr[10] = {};             // dynamic-LDS limit already set per kernel variant (bytes)
     int near_first = 0;               // PT_TRAVERSAL_*
     unsigned char *d_scratch = nullptr;   // this device's copy of the library's static scratch array
     void *rccl_comm = nullptr;        // communicator made by pt_comm_init_rank (owned)
@@ -202,6 +202,6 @@ int ptk_order_pixels(pt_context *ctx, int shift);
 int ptk_export_sorted(pt_context *ctx, pt_PrimitiveRayCS *d_out);
 int ptk_export_tree(pt_context *ctx);
 int ptk_primary(pt_context *ctx, const pt_camera *cam, const uint8_t *d_albedo);
-int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int mode);
+int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int mode, const int *region);
 int ptk_resolve(pt_context *ctx);
 int ptk_intersect(pt_context *ctx, const float *d_rays8, int n_rays, pt_hit *d_out);

@@ -172,6 +172,12 @@ __device__ __forceinline__ bool traverse(const SceneView &sc, const Ray &ray, ui
     }
 }
 
+// Material tables have PT_MAX_MATERIALS entries plus one all-zero entry: an id outside 0..15 (a
+// primitive or G-buffer texel the caller filled with something else) reads the zero material, as an
+// out-of-range constant-buffer read does in Direct3D 11, never memory beyond the table.
+constexpr int MAT_SLOTS = PT_MAX_MATERIALS + 1;
+__device__ __forceinline__ int mat_slot(int id) { return (int)min((unsigned)id, (unsigned)PT_MAX_MATERIALS); }
+
 // The four quotients of getBounce that depend on the material alone (ray_tracing.hlsl:263 nc/nt,
 // :284 R0, :303 ks.x/(tr+ks.x+kd.x), :307 1/ns), evaluated with the shader's own float expressions.
 __device__ __forceinline__ float4 material_quotients(const float4 m0, const float4 m1, const float4 m2)
@@ -189,6 +195,7 @@ __device__ __forceinline__ bool get_bounce(const float4 *mats, const float4 *mat
                                            pt_f3 &multi, pt_f3 &direction, uint32_t &seed)
 {
     direction = pt_mk3(0, 0, 0);
+    id = mat_slot(id);
     const float4 *mp = mats + 3 * id;
     const float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
     const float ke = m0.x, ns = m0.y, tr = m0.z, ni = m0.w;
@@ -385,9 +392,9 @@ constexpr int K_POP = -1, K_IDLE = -2, K_NOITEM = -3;
 #endif
 constexpr int EXPANSIONS = PT_EXPANSIONS;      // node expansions per pass of the traversal loop
 
-template <bool COUNT, bool LDSN>
+template <bool COUNT, bool LDSN, bool NEAR>
 __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const TriIsect *__restrict__ tri_sorted, int levels,
-                                                    int W, int H,
+                                                    unsigned n_slots,
                                                     const uint8_t *__restrict__ diffuse_tex,
                                                     const float4 *__restrict__ normal_tex,
                                                     const float4 *__restrict__ world_tex,
@@ -404,17 +411,17 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
     const int n = sc.n;
     const int nthreads = blockDim.x;
     float4 *lds_mats = lds_nodes + (LDSN ? 3 * n : 0);
-    float4 *lds_matq = lds_mats + 3 * PT_MAX_MATERIALS;
-    float *stack = reinterpret_cast<float *>(lds_matq + PT_MAX_MATERIALS) + threadIdx.x;   // level L at stack[(L-1) * nthreads]
+    float4 *lds_matq = lds_mats + 3 * MAT_SLOTS;
+    float *stack = reinterpret_cast<float *>(lds_matq + MAT_SLOTS) + threadIdx.x;   // level L at stack[(L-1) * nthreads]
     if (LDSN) {
         for (int i = threadIdx.x; i < 3 * n; i += nthreads) {
             const int node = i / 3, part = i - 3 * node;
             lds_nodes[i] = reinterpret_cast<const float4 *>(&sc.wide[node])[part];
         }
     }
-    if (threadIdx.x < 3 * PT_MAX_MATERIALS)
+    if (threadIdx.x < 3 * MAT_SLOTS)        // the device copy of the constants ends with the zero material
         lds_mats[threadIdx.x] = reinterpret_cast<const float4 *>(sc.cb->mats)[threadIdx.x];
-    if (threadIdx.x < PT_MAX_MATERIALS) {
+    if (threadIdx.x < MAT_SLOTS) {
         const float4 *mp = reinterpret_cast<const float4 *>(sc.cb->mats) + 3 * threadIdx.x;
         lds_matq[threadIdx.x] = material_quotients(mp[0], mp[1], mp[2]);
     }
@@ -423,9 +430,8 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
     const int REFILL_T = tune.refill_t, LEAF_T = tune.leaf_t, ITR_LIMIT = tune.itr_limit;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const unsigned npix = (unsigned)W * (unsigned)H;
     const unsigned chunks = (count + chunk - 1) / chunk;     // items per pixel
-    const unsigned total_items = npix * chunks;
+    const unsigned total_items = n_slots * chunks;           // n_slots pixels: the whole image, or the listed region
     const float4 *mats = lds_mats;
     const pt_f3 g_pos = pt_mk3(sc.cb->pos.v[0], sc.cb->pos.v[1], sc.cb->pos.v[2]);
     const float root_mn[3] = {sc.root[0], sc.root[1], sc.root[2]}, root_mx[3] = {sc.root[3], sc.root[4], sc.root[5]};
@@ -447,6 +453,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
     bool path_active = false;
     int cur_k = K_NOITEM, cur_s = 0, cur_id = 0;
     unsigned pending = 0;
+    unsigned pend_left = 0;             // NEAR only: levels whose pending child is the LEFT one
     uint32_t seed = 0;
     int itr = 1;
     pt_f3 multi = pt_mk3(0, 0, 0);
@@ -502,8 +509,8 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                         const uchar4 dif8 = reinterpret_cast<const uchar4 *>(diffuse_tex)[px];
                         const float4 nrm4 = normal_tex[px];
                         const float4 pos4 = world_tex[px];
-                        matid0 = __float_as_int(nrm4.w) - 1;            // asint(normal.w) - 1
-                        if (matid0 < 0) {
+                        matid0 = mat_slot(__float_as_int(nrm4.w) - 1);  // asint(normal.w) - 1
+                        if (__float_as_int(nrm4.w) <= 0) {
                             // ray_tracing.hlsl:361-362: black, but still accumulated every frame
                             for (uint32_t k = f; k < f_end; k++) { cnt.paths++; emit(pt_mk3(0, 0, 0), k); }
                         } else {
@@ -592,6 +599,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                         current_t = ray.t_max;
                         intersected = false;
                         pending = 0;
+                        pend_left = 0;
                         cnt.rays++;
                         if (COUNT) { cnt.node_visits++; cnt.box_tests++; }
                         float t_entry;
@@ -633,10 +641,25 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                     const int k = cur_k, half = 1 << (k - 1);
                     const int sr = cur_s + half, e = min(sr + half - 1, n);
                     const int kr = 32 - __clz(sr ^ e);
-                    if (hl && hr) { stack[__umul24((unsigned)(k - 1), (unsigned)nthreads)] = tr; pending |= 1u << k; }
-                    cur_k = hl ? k - 1 : (hr ? kr : K_POP);
-                    cur_id = hl ? sr - 1 : sr;
-                    cur_s = hl ? cur_s : sr;          // after a double miss only the bits above the pending levels matter
+                    if (NEAR) {
+                        // NON-PARITY option: of two children that both pass, the one the ray enters first is
+                        // visited first (ties: left, the reference's order); the other waits with ITS distance
+                        const bool right_first = hl && hr && tr < tl;
+                        if (hl && hr) {
+                            stack[__umul24((unsigned)(k - 1), (unsigned)nthreads)] = right_first ? tl : tr;
+                            pending |= 1u << k;
+                            if (right_first) pend_left |= 1u << k;
+                        }
+                        const bool go_left = hl && !right_first;
+                        cur_k = go_left ? k - 1 : (hr ? kr : K_POP);
+                        cur_id = go_left ? sr - 1 : sr;
+                        cur_s = go_left ? cur_s : sr;
+                    } else {
+                        if (hl && hr) { stack[__umul24((unsigned)(k - 1), (unsigned)nthreads)] = tr; pending |= 1u << k; }
+                        cur_k = hl ? k - 1 : (hr ? kr : K_POP);
+                        cur_id = hl ? sr - 1 : sr;
+                        cur_s = hl ? cur_s : sr;          // after a double miss only the bits above the pending levels matter
+                    }
                 }
         };
         auto pop = [&]() {
@@ -649,12 +672,15 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                         const int L = __ffs((int)pending) - 1;              // deepest pending ancestor level
                         pending &= pending - 1;
                         const float t_entry = stack[__umul24((unsigned)(L - 1), (unsigned)nthreads)];
+                        const bool left = NEAR && ((pend_left >> L) & 1u);
+                        if (NEAR) pend_left &= ~(1u << L);
                         if (t_entry <= current_t) {
                             const int sa = (cur_s >> L) << L, half = 1 << (L - 1);
                             const int sr = sa + half, e = min(sa + 2 * half - 1, n);
-                            cur_k = 32 - __clz(sr ^ e);
-                            cur_s = sr;
-                            cur_id = sr;
+                            // a left child covers its 2^(L-1) keys fully: level L - 1, named by its last key
+                            cur_k = left ? L - 1 : 32 - __clz(sr ^ e);
+                            cur_s = left ? sa : sr;
+                            cur_id = left ? sr - 1 : sr;
                         }
                     }
                 }
@@ -748,7 +774,6 @@ struct PathRec {                 // 48 bytes
 };
 struct HitRec { float t; int leaf; float bx, by; };   // leaf key of the hit; < 0: no hit
 
-constexpr int WF_MAX_RAYS = MAX_ITR * 3 - 1;           // rays of the longest path
 
 // appends the records of the lanes with `keep` to queue[*count ...] (one atomic per wave)
 __device__ __forceinline__ void wf_append(bool keep, const PathRec &rec, PathRec *__restrict__ queue,
@@ -792,10 +817,10 @@ __global__ __launch_bounds__(256) void k_wf_first(SceneView sc, int W, int H,
         if (slot < total) {
             const unsigned px = slot / count, fl = slot - px * count;
             const float4 nrm4 = normal_tex[px];
-            const int matid0 = __float_as_int(nrm4.w) - 1;              // asint(normal.w) - 1
+            const int matid0 = mat_slot(__float_as_int(nrm4.w) - 1);    // asint(normal.w) - 1
             cnt.paths++;
             pt_f3 color = pt_mk3(0, 0, 0);                              // ray_tracing.hlsl:361-362
-            if (matid0 >= 0) {
+            if (__float_as_int(nrm4.w) > 0) {
                 const unsigned y = px / (unsigned)W, x = px - y * (unsigned)W;
                 const uchar4 dif8 = reinterpret_cast<const uchar4 *>(diffuse_tex)[px];
                 const float4 pos4 = world_tex[px];
@@ -1088,13 +1113,19 @@ template <bool LINEAR>
 __global__ __launch_bounds__(256) void k_accumulate(const float4 *__restrict__ samples, size_t npix,
                                                     uint32_t first_frame, uint32_t count,
                                                     float4 *__restrict__ output, uint8_t *__restrict__ display,
-                                                    float4 *__restrict__ linear)
+                                                    float4 *__restrict__ linear, int W, int4 region)
 {
     __shared__ float4 tile[4][64][ACC_FRAMES + 1];        // +1: lanes of a wave land in different banks
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t p0 = (size_t)blockIdx.x * 256 + (size_t)wave * 64;       // the wave's first pixel
     const size_t p = p0 + lane;
-    const bool owner = p < npix;
+    bool owner = p < npix;
+    if (region.x >= 0) {
+        // a launch over a rectangle of the image (inclusive bounds, ray_tracing.hlsl:402-406): pixels
+        // outside it keep their values
+        const int y = (int)(p / (size_t)W), x = (int)(p - (size_t)y * (size_t)W);
+        owner = owner && x >= region.x && x <= region.z && y >= region.y && y <= region.w;
+    }
     float4 acc = make_float4(0, 0, 0, 0);
     if (owner) acc = LINEAR ? linear[p] : output[p];
     const float inv_gamma = 1 / 2.2f;
@@ -1136,6 +1167,15 @@ __global__ __launch_bounds__(256) void k_accumulate(const float4 *__restrict__ s
             make_uchar4((unsigned char)to_unorm8(acc.x), (unsigned char)to_unorm8(acc.y),
                         (unsigned char)to_unorm8(acc.z), (unsigned char)to_unorm8(acc.w));
     }
+}
+
+// pixel ids of the rectangle [x0, x0 + rw) x [y0, y0 + rh), row by row: the work list of a region launch
+__global__ __launch_bounds__(256) void k_region_list(int W, int x0, int y0, int rw, unsigned count, uint32_t *__restrict__ out)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const unsigned ry = i / (unsigned)rw, rx = i - ry * (unsigned)rw;
+    out[i] = (unsigned)(y0 + (int)ry) * (unsigned)W + (unsigned)(x0 + (int)rx);
 }
 
 // out = pow(sum.rgb / sum.a, 1/2.2), alpha 1
@@ -1198,7 +1238,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_primary(SceneView sc, CamBasi
         const pt_f3 nn = pt_normalize3(pt_add3(pt_add3(pt_scale3(nA, bary.z), pt_scale3(nB, bary.x)), pt_scale3(nC, bary.y)));
         const pt_f3 pp = pt_add3(pt_add3(pt_scale3(pA, bary.z), pt_scale3(pB, bary.x)), pt_scale3(pC, bary.y));
         const int matid = pr->matid;
-        dif = albedo[matid];
+        if ((unsigned)matid < (unsigned)PT_MAX_MATERIALS) dif = albedo[matid];    // a 16-entry table
         dif.w = 255;
         nrm = make_float4(nn.x, nn.y, nn.z, __int_as_float(matid + 1));
         pos = make_float4(pp.x, pp.y, pp.z, 1.0f);
@@ -1275,7 +1315,7 @@ static int lds_resident_threads(const pt_context *ctx, int *levels_out, size_t *
 {
     const size_t lds_total = 160 * 1024;
     const int levels = 32 - __builtin_clz((unsigned)ctx->n | 1u);
-    const size_t nodes = (size_t)ctx->n * 48 + PT_MAX_MATERIALS * 64;      // + materials and their quotients
+    const size_t nodes = (size_t)ctx->n * 48 + MAT_SLOTS * 64;             // + materials and their quotients
     if (nodes + (size_t)levels * 4 * 256 > lds_total) return 0;
     size_t t = (lds_total - nodes) / ((size_t)levels * 4);
     t = t > 1024 ? 1024 : (t / 64) * 64;
@@ -1293,27 +1333,45 @@ static uint32_t frames_per_launch(const pt_context *ctx, uint32_t count, bool wa
     // persistent schedule: up to an eighth of the device's memory (36 GiB of 288), at least 4 GiB -- at
     // 3840x2160 a 128-frame launch (17 GB of samples) is 6 % faster than four 32-frame launches
     size_t bytes = wavefront ? ((size_t)1 << 30) : (ctx->samples_cap_bytes > ((size_t)4 << 30) ? ctx->samples_cap_bytes : ((size_t)4 << 30));
-    if (const char *e = getenv("PTAMD_SAMPLES_GIB")) if (atoi(e) > 0) bytes = (size_t)atoi(e) << 30;
+    if (ctx->knobs.samples_gib > 0) bytes = (size_t)ctx->knobs.samples_gib << 30;
     size_t cap = bytes / per_frame;
     if (cap < 1) cap = 1;
     return (uint32_t)(count < cap ? count : cap);
 }
 
-int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int mode)
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel variant and context (again only
+// when a later launch needs more)
+template <typename F>
+static int ensure_lds_limit(pt_context *ctx, int slot, F kernel, size_t lds_bytes)
+{
+    if (ctx->lds_attr[slot] >= (int)lds_bytes) return PT_OK;
+    PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    ctx->lds_attr[slot] = (int)lds_bytes;
+    return PT_OK;
+}
+
+static int timing_event(pt_context *ctx, hipEvent_t *ev)
+{
+    if (!ctx->event_pool.empty()) { *ev = ctx->event_pool.back(); ctx->event_pool.pop_back(); return PT_OK; }
+    PT_HIP(ctx, hipEventCreate(ev));
+    return PT_OK;
+}
+
+// region: null = the whole image, else {x0, y0, x1, y1} inclusive and inside the image
+int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int mode, const int *region)
 {
     SceneView sv;
     if (int rc = make_view(ctx, sv)) return rc;
-    Tuning tune = {20, 12, ctx->itr_limit};
-    if (const char *e = getenv("PTAMD_REFILL_T")) tune.refill_t = atoi(e);
-    if (const char *e = getenv("PTAMD_LEAF_T")) tune.leaf_t = atoi(e);
+    const Knobs &kn = ctx->knobs;
+    Tuning tune = {kn.refill_t, kn.leaf_t, ctx->itr_limit};
     const bool lin = (mode == PT_ACCUM_LINEAR);
     const size_t npix = (size_t)ctx->W * ctx->H;
     int levels = 0;
     size_t lds_bytes = 0;
     int threads = lds_resident_threads(ctx, &levels, &lds_bytes);
-    if (const char *e = getenv("PTAMD_NO_LDS_TREE")) if (atoi(e)) threads = 0;
-    if (const char *e = getenv("PTAMD_MAX_THREADS")) {      // occupancy experiments: fewer waves per CU
-        const int cap = (atoi(e) / 64) * 64;
+    if (kn.no_lds_tree) threads = 0;
+    if (kn.max_threads) {      // occupancy experiments: fewer waves per CU
+        const int cap = (kn.max_threads / 64) * 64;
         if (cap >= 256 && threads > cap) { lds_bytes -= (size_t)levels * 4 * (size_t)(threads - cap); threads = cap; }
     }
     const bool lds_nodes = threads >= 256;          // else: node records stay in global memory
@@ -1321,12 +1379,12 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
         // LDS holds the materials and one float per tree level and lane
         levels = 32 - __builtin_clz((unsigned)ctx->n | 1u);
         threads = 1024;
-        lds_bytes = PT_MAX_MATERIALS * 64 + (size_t)levels * 4 * threads;
+        if (kn.max_threads >= 256) threads = (kn.max_threads / 64) * 64;
+        lds_bytes = MAT_SLOTS * 64 + (size_t)levels * 4 * threads;
     }
-    static const bool no_order = getenv("PTAMD_NO_ORDER") && atoi(getenv("PTAMD_NO_ORDER"));
-
-    bool wavefront = lds_nodes && ctx->schedule == PT_SCHEDULE_WAVEFRONT;
-    if (const char *e = getenv("PTAMD_MEGAKERNEL")) wavefront = lds_nodes && !atoi(e);   // A/B runs
+    const bool near_first = ctx->near_first != 0;
+    // the wavefront schedule exists for whole-image launches in the reference's visit order
+    const bool wavefront = lds_nodes && ctx->schedule == PT_SCHEDULE_WAVEFRONT && !region && !near_first;
     const uint32_t per_launch = frames_per_launch(ctx, count, wavefront);
     if (ctx->samples_frames < per_launch) {
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1349,6 +1407,16 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
         PT_HIP(ctx, hipMalloc((void **)&ctx->d_wf_hits, recs * sizeof(HitRec)));
         ctx->wf_paths = paths;
     }
+    // a region launch walks a list of the rectangle's pixel ids (d_okeys[1]: scratch of the pixel sort otherwise)
+    unsigned n_slots = (unsigned)npix;
+    int4 reg = make_int4(-1, -1, -1, -1);
+    if (region) {
+        const int rw = region[2] - region[0] + 1, rh = region[3] - region[1] + 1;
+        n_slots = (unsigned)rw * (unsigned)rh;
+        reg = make_int4(region[0], region[1], region[2], region[3]);
+        hipLaunchKernelGGL(k_region_list, dim3((n_slots + 255) / 256), dim3(256), 0, ctx->stream, ctx->W, region[0], region[1], rw, n_slots,
+                           ctx->d_okeys[1]);
+    }
 
     for (uint32_t off = 0; off < count; off += per_launch) {
         const uint32_t cnt = (count - off < per_launch) ? count - off : per_launch;
@@ -1358,12 +1426,12 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
         if (ctx->time_trace) {
             // bounded history: a caller that never reads the times keeps the latest 4096 launches
             if (ctx->trace_events.size() >= 4096) {
-                (void)hipEventDestroy(ctx->trace_events.front().first);
-                (void)hipEventDestroy(ctx->trace_events.front().second);
+                ctx->event_pool.push_back(ctx->trace_events.front().first);
+                ctx->event_pool.push_back(ctx->trace_events.front().second);
                 ctx->trace_events.erase(ctx->trace_events.begin());
             }
-            PT_HIP(ctx, hipEventCreate(&ev_begin));
-            PT_HIP(ctx, hipEventCreate(&ev_end));
+            if (int rc = timing_event(ctx, &ev_begin)) return rc;
+            if (int rc = timing_event(ctx, &ev_end)) return rc;
             ctx->trace_events.emplace_back(ev_begin, ev_end);
         }
         if (wavefront) {
@@ -1376,14 +1444,12 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             PathRec *queue[2] = {static_cast<PathRec *>(ctx->d_wf_queue[0]), static_cast<PathRec *>(ctx->d_wf_queue[1])};
             HitRec *hits = static_cast<HitRec *>(ctx->d_wf_hits);
             const dim3 fgrid((unsigned)ctx->num_cus * 8u), sgrid(32, WF_SEGS);
-            Tuning wt = {16, 12, ctx->itr_limit};
-            if (const char *e = getenv("PTAMD_WF_REFILL_T")) wt.refill_t = atoi(e);
-            if (const char *e = getenv("PTAMD_WF_LEAF_T")) wt.leaf_t = atoi(e);
+            Tuning wt = {kn.wf_refill_t, kn.wf_leaf_t, ctx->itr_limit};
+            if (int rc = ensure_lds_limit(ctx, 8, &k_wf_extend<false>, lds_bytes)) return rc;
+            if (int rc = ensure_lds_limit(ctx, 9, &k_wf_extend<true>, lds_bytes)) return rc;
             if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream));
             hipLaunchKernelGGL(k_wf_first, fgrid, dim3(256), 0, ctx->stream, sv, ctx->W, ctx->H, ctx->d_diffuse, ctx->d_normal,
                                ctx->d_world, first, cnt, seeds, ctx->d_samples, queue[0], qcount + per_depth, seg_size, ctx->d_counters);
-            PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_extend<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_extend<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             for (int d = 1; d <= ctx->itr_limit - 1; d++) {          // a path is at most itr_limit - 1 rays long
                 PathRec *qin = queue[(d - 1) & 1], *qout = queue[d & 1];
                 if (ctx->detailed)
@@ -1397,47 +1463,42 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             }
             if (ev_end) PT_HIP(ctx, hipEventRecord(ev_end, ctx->stream));
             PT_HIP(ctx, hipGetLastError());
-            if (getenv("PTAMD_PRINT_WF")) {      // diagnostics: queue length per depth
-                std::vector<unsigned> h(32 * per_depth);
-                PT_HIP(ctx, hipMemcpyAsync(h.data(), ctx->d_wf_counts, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-                PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                fprintf(stderr, "wf queue lengths:");
-                for (int d = 1; d <= WF_MAX_RAYS + 1; d++) {
-                    unsigned long long t = 0;
-                    for (int k = 0; k < WF_SEGS; k++) t += h[d * per_depth + (size_t)k * WF_CSTRIDE];
-                    fprintf(stderr, " %llu", t);
-                }
-                fprintf(stderr, "\n");
-            }
         } else {
             // frames per work item: about 16 items per lane, so that the launch ends on short
             // items, in equal parts of the launch's frames
             const unsigned long long lanes = (unsigned long long)ctx->num_cus * threads;
-            unsigned long long chunk = ((unsigned long long)cnt * npix) / (lanes * 16ull);
+            unsigned long long chunk = ((unsigned long long)cnt * n_slots) / (lanes * 16ull);
             if (chunk < 1) chunk = 1;
             if (chunk > cnt) chunk = cnt;
             chunk = (cnt + (cnt + chunk - 1) / chunk - 1) / ((cnt + chunk - 1) / chunk);
-            if (const char *e = getenv("PTAMD_CHUNK")) { chunk = (unsigned long long)atoi(e); if (chunk < 1) chunk = 1; if (chunk > cnt) chunk = cnt; }
+            if (kn.chunk > 0) { chunk = (unsigned long long)kn.chunk; if (chunk > cnt) chunk = cnt; }
             // With few items per lane the launch ends ragged unless the expensive pixels go first; with
             // many, image order (neighbouring pixels, similar paths in a wave) is the better order.
-            const unsigned long long items = (unsigned long long)npix * ((cnt + chunk - 1) / chunk);
-            const bool ordered = !no_order && items < 32ull * lanes;
-            if (!ordered) ctx->order_valid = false;
+            const unsigned long long items = (unsigned long long)n_slots * ((cnt + chunk - 1) / chunk);
+            const bool ordered = !region && !kn.no_order && items < 32ull * lanes;
+            if (!ordered && !region) ctx->order_valid = false;
+            const uint32_t *order = region ? ctx->d_okeys[1] : (ctx->order_valid ? ctx->d_ovals[0] : (const uint32_t *)nullptr);
             PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
             int frame_lanes_log2 = 0;                    // lanes per pixel: the largest power of two <= count, at most 256
             while (frame_lanes_log2 < 8 && (2u << frame_lanes_log2) <= cnt) frame_lanes_log2++;
             hipLaunchKernelGGL(k_path_seeds, dim3((unsigned)ctx->num_cus * 16u), dim3(256), 0, ctx->stream, ctx->W, (unsigned)npix, cnt,
                                seeds, ctx->d_samples, frame_lanes_log2);
-#define PT_LAUNCH(C, L) do { \
-            PT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_persistent<C, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-            hipLaunchKernelGGL((k_trace_persistent<C, L>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
-                ctx->W, ctx->H, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, seeds, \
+#define PT_LAUNCH(SLOT, C, L, N) do { \
+            if (int rc_ = ensure_lds_limit(ctx, SLOT, &k_trace_persistent<C, L, N>, lds_bytes)) return rc_; \
+            if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream)); \
+            hipLaunchKernelGGL((k_trace_persistent<C, L, N>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
+                n_slots, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, seeds, \
                 ctx->d_samples, ctx->d_counters, ctx->d_work, \
-                ctx->order_valid ? ctx->d_ovals[0] : (const uint32_t *)nullptr, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, \
+                order, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, \
                 (uint32_t)chunk, tune); } while (0)
-            if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream));
-            if (lds_nodes) { if (ctx->detailed) PT_LAUNCH(true, true); else PT_LAUNCH(false, true); }
-            else           { if (ctx->detailed) PT_LAUNCH(true, false); else PT_LAUNCH(false, false); }
+            // slot of the variant in ctx->lds_attr: COUNT, LDSN, NEAR as bits
+            if (near_first) {
+                if (lds_nodes) { if (ctx->detailed) PT_LAUNCH(7, true, true, true); else PT_LAUNCH(6, false, true, true); }
+                else           { if (ctx->detailed) PT_LAUNCH(5, true, false, true); else PT_LAUNCH(4, false, false, true); }
+            } else {
+                if (lds_nodes) { if (ctx->detailed) PT_LAUNCH(3, true, true, false); else PT_LAUNCH(2, false, true, false); }
+                else           { if (ctx->detailed) PT_LAUNCH(1, true, false, false); else PT_LAUNCH(0, false, false, false); }
+            }
 #undef PT_LAUNCH
             if (ev_end) PT_HIP(ctx, hipEventRecord(ev_end, ctx->stream));
             PT_HIP(ctx, hipGetLastError());
@@ -1452,9 +1513,9 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
         }
         const dim3 agrid((unsigned)((npix + 255) / 256));
         if (lin) hipLaunchKernelGGL(k_accumulate<true>, agrid, dim3(256), 0, ctx->stream, ctx->d_samples, npix, first, cnt,
-                                    ctx->d_output, ctx->d_display, ctx->d_linear);
+                                    ctx->d_output, ctx->d_display, ctx->d_linear, ctx->W, reg);
         else     hipLaunchKernelGGL(k_accumulate<false>, agrid, dim3(256), 0, ctx->stream, ctx->d_samples, npix, first, cnt,
-                                    ctx->d_output, ctx->d_display, ctx->d_linear);
+                                    ctx->d_output, ctx->d_display, ctx->d_linear, ctx->W, reg);
         PT_HIP(ctx, hipGetLastError());
     }
     return PT_OK;

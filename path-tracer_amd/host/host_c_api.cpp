@@ -68,6 +68,12 @@ int pth_tracer_read(RayTracer *r, float *rgba32f, uint8_t *rgba8)
     if (rgba8) { auto v = r->readDisplay(); std::memcpy(rgba8, v.data(), v.size()); }
     return r->ok() ? 0 : -1;
 }
+int pth_tracer_frame_count(const RayTracer *r) { return r->frame_count; }
+// what the application does to the public members: the ACC toggle writes frame_count (CS.cpp:524-527),
+// the window callback calls resize (CS.cpp:205)
+void pth_tracer_set_frame_count(RayTracer *r, int v) { r->frame_count = v; }
+int pth_tracer_resize(RayTracer *r, int w, int h) { r->resize(w, h); return r->ok() ? 0 : -1; }
+void pth_tracer_set_tiles(RayTracer *r, int tx, int ty) { r->tiles_x = tx; r->tiles_y = ty; }
 int pth_tracer_members(RayTracer *r, pt_Bound *bb, pt_PrimitiveRay *sorted_rays, pt_TreeNode *tree)
 {
     if (bb) *bb = r->bb_;

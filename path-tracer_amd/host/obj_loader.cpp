@@ -1,3 +1,7 @@
+// OBJ / MTL reader of the host facade.  Own code, except that read_double below follows the decimal
+// reader of tinyobjloader v1.1.1 (tryParseDouble; Copyright (c) 2012-2018 Syoyo Fujita and many
+// contributors, MIT licence -- the parser the reference application vendors as tiny_obj_loader.h):
+// parsed floats must match that parser bit for bit, so its digit-by-digit arithmetic is reproduced.
 #include "obj_loader.hpp"
 
 #include <cmath>
@@ -86,12 +90,15 @@ struct Cursor {
     bool at_end() const { return *p == '\0' || *p == '\r' || *p == '\n'; }
 };
 
-// 1-based / negative-relative OBJ index -> 0-based; zero is invalid
-bool fix_index(int idx, int count, int &out)
+// 1-based / negative-relative OBJ index -> 0-based.  Zero is invalid, and so is anything that does not
+// name one of the `count` elements read so far (faces are triangulated from the vertices present when
+// their group is closed, so a reference can never point forward).
+bool fix_index(int idx, int count, int &out, bool dereferenced = true)
 {
-    if (idx > 0) { out = idx - 1; return true; }
-    if (idx < 0) { out = count + idx; return true; }
-    return false;
+    if (idx > 0) out = idx - 1;
+    else if (idx < 0) out = count + idx;
+    else return false;
+    return !dereferenced || (out >= 0 && out < count);
 }
 
 void skip_index_field(const char *&p) { p += std::strcspn(p, "/ \t\r"); }
@@ -111,7 +118,7 @@ bool read_corner(const char *&p, int nv, int nvn, int nvt, Index &out)
         out = c;
         return true;
     }
-    if (!fix_index(std::atoi(p), nvt, c.vt)) return false;
+    if (!fix_index(std::atoi(p), nvt, c.vt, false)) return false;     // texture coordinates are parsed, never read
     skip_index_field(p);
     if (*p != '/') { out = c; return true; }
     p++;

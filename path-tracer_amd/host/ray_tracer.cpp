@@ -27,6 +27,12 @@ void RayTracer::loadScene(const char *filename)
     flush();
     error_.clear();
     if (!scene.loadObj(filename)) { error_ = "loadObj: " + scene.error; return; }
+    // the constant buffer holds 16 materials (structs.hlsli); the reference indexes past it silently
+    if (scene.materials_.size() > (size_t)PT_MAX_MATERIALS) {
+        error_ = "loadScene: " + std::to_string(scene.materials_.size()) + " materials (the default one included); the constant buffer holds " +
+                 std::to_string(PT_MAX_MATERIALS);
+        return;
+    }
 
     // shape -> material group -> face order; global index; pad = -1
     renderer_primitives.resize((size_t)scene.triangle_count);
@@ -162,6 +168,19 @@ void RayTracer::trace()
         for (int i = 1; i < 16; i++) (void)dist(rd);
     } else {
         pt_frame_seeds(base_seed, (uint32_t)frame_count, 1, &seed);
+    }
+    if (tiles_x > 1 || tiles_y > 1) {
+        // ray_tracer.cpp:302-332: for (w = 0; w < width; w += width / TILEX) for (h = 0; h < height; h += height / TILEY),
+        // offset = {w, h, w + width / TILEX - 1, h + height / TILEY - 1}.  As there, a width that TILEX does not
+        // divide gets one more, narrower column of tiles (the bounds are clipped to the image by the library).
+        flush();
+        const int tw = width / tiles_x, th = height / tiles_y;
+        if (tw < 1 || th < 1) { error_ = "trace: more tiles than pixels"; return; }
+        for (int w = 0; w < width; w += tw)
+            for (int h = 0; h < height; h += th)
+                if (!check(pt_trace_region(ctx_, (uint32_t)frame_count, seed, w, h, w + tw - 1, h + th - 1), "pt_trace_region")) return;
+        frame_count += 1;
+        return;
     }
     // a caller that moved frame_count (the reference's ACC toggle sets it to 0) starts a new batch
     if (!pending_seeds_.empty() && frame_count != pending_first_ + (int)pending_seeds_.size()) flush();

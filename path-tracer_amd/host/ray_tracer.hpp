@@ -69,6 +69,12 @@ public:
     // one launch per frame; a launch of 32 frames takes half the time of 32 launches.  1 = launch in run().
     int frames_per_launch = 32;
     void flush();
+    // the reference's TILEX / TILEY (ray_tracer.cpp:298-299, compiled as 1): the image is traced in
+    // tiles_x * tiles_y dispatches per frame, each over width / tiles_x by height / tiles_y pixels with
+    // the offset and inclusive bounds of ray_tracer.cpp:319-322.  The reference draws a new seed per
+    // tile; here every tile of a frame uses the frame's seed, so the image does not depend on the tiling.
+    // Values above 1 launch inside run() (frames are not batched).
+    int tiles_x = 1, tiles_y = 1;
     float eye[3] = {0.0f, 5.0f, 23.0f};                 // CS.cpp:49
     float at[3] = {0.0f, 5.0f, 0.0f};                   // CS.cpp:50
     // material constants + eye into CB_Radix (reference: CS.cpp:405-439)

@@ -33,6 +33,8 @@ PT_ACCUM_LITERAL = 0
 PT_ACCUM_LINEAR = 1
 PT_SCHEDULE_PERSISTENT = 0
 PT_SCHEDULE_WAVEFRONT = 1
+PT_TRAVERSAL_REFERENCE = 0
+PT_TRAVERSAL_NEAR_FIRST = 1
 STAGES = ("bounds", "morton", "sort", "topology", "refit", "pack")
 
 # every symbol include/ptamd.h declares
@@ -43,10 +45,11 @@ EXPORTS = (
     "pt_download_scene_bound", "pt_download_morton", "pt_download_permutation",
     "pt_download_sorted_primitives", "pt_download_tree",
     "pt_resize", "pt_upload_gbuffer", "pt_download_gbuffer", "pt_primary_hits", "pt_albedo_bytes",
-    "pt_trace", "pt_trace_frames", "pt_frame_seeds", "pt_get_frame_count", "pt_reset_accumulation",
+    "pt_trace", "pt_trace_region", "pt_trace_frames", "pt_frame_seeds", "pt_get_frame_count", "pt_reset_accumulation",
     "pt_linear_sum_device_ptr", "pt_resolve",
+    "pt_comm_unique_id", "pt_comm_init_rank", "pt_comm_destroy", "pt_reduce_linear_sum",
     "pt_download_output", "pt_download_display", "pt_output_device_ptr",
-    "pt_set_stack_size", "pt_set_max_segments", "pt_set_trace_schedule", "pt_set_trace_timing", "pt_get_trace_times", "pt_set_detailed_counters", "pt_get_counters", "pt_reset_counters", "pt_intersect",
+    "pt_set_stack_size", "pt_set_max_segments", "pt_set_traversal_order", "pt_set_trace_schedule", "pt_set_trace_timing", "pt_get_trace_times", "pt_set_detailed_counters", "pt_get_counters", "pt_reset_counters", "pt_intersect",
 )
 
 
@@ -104,6 +107,15 @@ def frame_seeds(base_seed, first, count):
     out = np.zeros(count, dtype=np.uint32)
     load().pt_frame_seeds(C.c_uint32(base_seed), C.c_uint32(first), C.c_uint32(count), out.ctypes.data_as(C.c_void_p))
     return out
+
+
+def unique_comm_id():
+    """128-byte id for comm_init_rank (ncclGetUniqueId through the library); made on ONE rank."""
+    buf = (C.c_char * 128)()
+    rc = load().pt_comm_unique_id(buf)
+    if rc != 0:
+        raise PtError(f"pt_comm_unique_id failed ({rc}): {load().pt_last_error(None).decode()}")
+    return bytes(buf.raw)
 
 
 def albedo_table(kd_rows, srgb_quirk=True):
@@ -242,6 +254,10 @@ class Context:
     def trace(self, framecount, seed):
         self._ck(self.L.pt_trace(self.h, C.c_uint32(framecount), C.c_uint32(int(seed))))
 
+    def trace_region(self, framecount, seed, x0, y0, x1, y1):
+        self._ck(self.L.pt_trace_region(self.h, C.c_uint32(framecount), C.c_uint32(int(seed)),
+                                        C.c_int(x0), C.c_int(y0), C.c_int(x1), C.c_int(y1)))
+
     def trace_frames(self, first, seeds, mode=PT_ACCUM_LITERAL):
         seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
         self._ck(self.L.pt_trace_frames(self.h, C.c_uint32(first), C.c_uint32(len(seeds)), _p(seeds), C.c_int(mode)))
@@ -262,6 +278,18 @@ class Context:
 
     def resolve(self):
         self._ck(self.L.pt_resolve(self.h))
+
+    # -- multi-GPU merge (RCCL behind the C ABI) ------------------------------
+    def comm_init_rank(self, n_ranks, rank, comm_id):
+        """comm_id: the 128 bytes of unique_comm_id() made on rank 0."""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(comm_id))
+        self._ck(self.L.pt_comm_init_rank(self.h, C.c_int(n_ranks), C.c_int(rank), buf))
+
+    def comm_destroy(self):
+        self._ck(self.L.pt_comm_destroy(self.h))
+
+    def reduce_linear_sum(self, nccl_comm=None):
+        self._ck(self.L.pt_reduce_linear_sum(self.h, C.c_void_p(nccl_comm)))
 
     def output(self):
         a = np.zeros((self.H, self.W, 4), dtype=np.float32)
@@ -291,6 +319,9 @@ class Context:
 
     def set_max_segments(self, segments):
         self._ck(self.L.pt_set_max_segments(self.h, C.c_int(segments)))
+
+    def set_traversal_order(self, order):
+        self._ck(self.L.pt_set_traversal_order(self.h, C.c_int(order)))
 
     def set_trace_schedule(self, schedule):
         self._ck(self.L.pt_set_trace_schedule(self.h, C.c_int(schedule)))

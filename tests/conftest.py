@@ -54,6 +54,45 @@ def make_soup(n, seed=12345, dtype=None):
     return prims
 
 
+def device_soup(n, seed=12345, scale=1.0, emitter_every=0, device="cuda"):
+    """The same kind of soup generated ON the GPU with torch (no host copy: 50M-100M triangles), as an (n, 20)
+    float32 tensor in the PrimitiveRender layout.  emitter_every = k: every k-th triangle gets material 4 (the
+    emitter of soup_cb5), the others cycle through materials 0..3.  Not the same numbers as make_soup."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    e = 0.5 * max(n, 1) ** (-1.0 / 3.0)
+    out = torch.zeros((n, 20), dtype=torch.float32, device=device)
+    c = torch.rand((n, 3), generator=g, device=device)
+    out[:, 0:3] = c * scale
+    out[:, 6:9] = (c + (torch.rand((n, 3), generator=g, device=device) * 2 - 1) * e) * scale
+    out[:, 12:15] = (c + (torch.rand((n, 3), generator=g, device=device) * 2 - 1) * e) * scale
+    del c
+    for k in (3, 9, 15):
+        out[:, k:k + 3] = torch.rand((n, 3), generator=g, device=device) * 2 - 1
+    ids = out.view(torch.int32)
+    i = torch.arange(n, device=device, dtype=torch.int32)
+    ids[:, 18] = i % 4
+    if emitter_every:
+        ids[:, 18] = torch.where(i % emitter_every == 0, torch.full_like(i, 4), i % 4)
+    ids[:, 19] = -1
+    torch.cuda.synchronize()
+    return out
+
+
+def soup_cb5(n, eye=(0.5, 0.5, 3.0)):
+    """Materials of the large synthetic configuration: 4 diffuse + 1 emissive."""
+    from oracle import orc
+    cb = np.zeros(1, dtype=orc.CB_RADIX)
+    cb["node_count"] = n
+    cb["pos"][0] = eye
+    m = cb["mats"][0]
+    for k, kd in enumerate(((0.7, 0.6, 0.5), (0.3, 0.6, 0.7), (0.6, 0.7, 0.3), (0.75, 0.75, 0.75))):
+        m[k]["ns"] = 1; m[k]["ni"] = 1; m[k]["kd"][:3] = kd
+    m[4]["ke"] = 10; m[4]["ns"] = 1; m[4]["ni"] = 1; m[4]["kd"][:3] = (1, 1, 1)
+    return cb
+
+
 def soup_cb(n, eye=(0.5, 0.5, 3.0)):
     """4 diffuse-ish materials + 1 emitter, for soups."""
     from oracle import orc

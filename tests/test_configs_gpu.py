@@ -1,0 +1,202 @@
+"""GPU: the named benchmark configurations that are larger than the reference's four scenes, each at the
+bar its size allows.
+
+  * LBVH build of a 50M-triangle soup: size-independent properties (sortedness with stable ties, permutation,
+    every box the union of its children, parents, leaves), soup generated on the device.
+  * The option set of the 100M-triangle render -- full-resolution codes (PT_BUILD_MORTON_FULL), deep stack,
+    pt_set_max_segments(8), node records in global memory, 4 diffuse + 1 emissive material -- against the
+    oracle run with exactly those options, bit for bit, at n = 200k; then at the full 100M / 3840x2160 size
+    through properties (sample counts, finite sums, identical counters and image on a second run).
+  * The non-parity traversal order (PT_TRAVERSAL_NEAR_FIRST) against the oracle's restatement of it, and
+    against the reference order on the reference's scenes.
+All of these are NON-PARITY configurations except the 50M build: the reference's 15-entry stack drops
+subtrees of trees this deep and its codes have 22 cells per axis."""
+import numpy as np
+import pytest
+
+import ptamd
+from oracle import orc
+from conftest import SCENES, device_soup, make_soup, soup_cb5
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint8)
+
+
+CAM = dict(eye=(50.0, 50.0, 300.0), at=(50.0, 50.0, 50.0))
+
+
+def _soup_setup(ctx, prims, W, H, flags, near_first=False):
+    n = len(prims)
+    cb = soup_cb5(n, eye=CAM["eye"])
+    ctx.upload_primitives(prims); ctx.set_constants(cb); ctx.build(flags); ctx.resize(W, H)
+    ctx.set_stack_size(32)
+    ctx.set_max_segments(8)
+    ctx.set_traversal_order(ptamd.PT_TRAVERSAL_NEAR_FIRST if near_first else ptamd.PT_TRAVERSAL_REFERENCE)
+    alb = ptamd.albedo_table([list(cb["mats"][0][m]["kd"][:3]) for m in range(16)])
+    cam = ptamd.default_camera(**CAM); cam.zfar = 1000.0
+    ctx.primary_hits(cam, alb)
+    return cb, alb
+
+
+@pytest.mark.parametrize("near_first", [False, True])
+def test_large_scene_option_set_against_the_oracle(gpu_ctx_factory, near_first):
+    """n = 200k (18 levels, node records 9.6 MB: global memory), full-resolution codes, stack 32, at most 8
+    rays per path, 4 diffuse + 1 emissive material, cube scaled to 100 units (the triangle test rejects
+    |det| <= 1e-4 on unnormalised edges, ray_tracing.hlsl:172).  Library == oracle with the same options."""
+    n, W, H = 200_000, 200, 150
+    prims = make_soup(n, seed=4242, dtype=ptamd.PRIM_RENDER)
+    prims["vertices"]["pos"] *= np.float32(100.0)
+    prims["matid"] = np.where(np.arange(n) % 16 == 0, 4, np.arange(n) % 4)
+    ctx = gpu_ctx_factory()
+    cb, alb = _soup_setup(ctx, prims, W, H, ptamd.PT_BUILD_MORTON_FULL, near_first)
+    ob = orc.build_full_codes(prims.view(orc.PRIM_RENDER))
+    assert np.array_equal(ctx.morton(), ob["rays"]["morton_code"])
+    assert np.array_equal(ctx.permutation(), ob["sorted_rays"]["index"])
+    assert ctx.tree().tobytes() == ob["tree"][:2 * n].tobytes()
+    ocam = orc.default_camera(**CAM); ocam.zfar = 1000.0
+    sc = orc.OracleScene(prims.view(orc.PRIM_RENDER), ob["tree"], cb, stack_size=64, max_segments=8, near_first=near_first)
+    # the G-buffer pass always visits in the reference's order
+    gb = orc.primary(orc.OracleScene(prims.view(orc.PRIM_RENDER), ob["tree"], cb, stack_size=64), ocam, W, H, alb)
+    d, nn, w = ctx.download_gbuffer()
+    assert np.array_equal(d, gb[0]) and np.array_equal(_bits(nn), _bits(gb[1])) and np.array_equal(_bits(w), _bits(gb[2]))
+    ctx.set_detailed_counters(True)
+    seeds = ptamd.frame_seeds(1, 0, 2)
+    ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LINEAR)
+    acc = np.zeros((H, W, 4), np.float32)
+    tot = dict(paths=0, rays=0, node_visits=0, box_tests=0, tri_tests=0)
+    for f in range(2):
+        c = orc.trace_frame_linear(sc, gb, f, seeds[f], acc)
+        tot = {k: tot[k] + c[k] for k in tot}
+    assert np.array_equal(_bits(ctx.linear_sum()), _bits(acc))
+    got = ctx.counters()
+    assert got["paths"] == tot["paths"] and got["rays"] == tot["rays"] and got["tri_tests"] == tot["tri_tests"]
+    # node visits: the library counts both children at every expansion, the oracle every pop; with the
+    # reference's order these are the same events, nearest-first the oracle's ordering tests are not counted
+    assert got["node_visits"] == tot["node_visits"]
+    assert 0.5 * tot["paths"] < tot["rays"] <= 8 * tot["paths"]
+    print("near_first", near_first, "visits/ray", got["node_visits"] / got["rays"], "tests/ray", got["tri_tests"] / got["rays"])
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_near_first_order_on_the_reference_scenes(gpu_ctx_factory, golden, scene):
+    """PT_TRAVERSAL_NEAR_FIRST on the reference's scenes (tree in LDS): equal to the oracle's restatement of the
+    same order bit for bit; against the reference's order the images may differ only where two triangles are hit
+    at (nearly) the same distance -- counted and bounded here."""
+    W, H = 160, 136
+    g = golden[scene]
+    ctx = gpu_ctx_factory()
+    ctx.upload_primitives(g["prims"]); ctx.set_constants(g["cb"]); ctx.build(); ctx.resize(W, H)
+    alb = ptamd.albedo_table(g["mat_table"][:, 0:3], True)
+    ctx.primary_hits(ptamd.default_camera(), alb)
+    gb = ctx.download_gbuffer()
+    seeds = ptamd.frame_seeds(1, 0, 4)
+    res = {}
+    for near in (False, True):
+        ctx.set_traversal_order(ptamd.PT_TRAVERSAL_NEAR_FIRST if near else ptamd.PT_TRAVERSAL_REFERENCE)
+        ctx.set_detailed_counters(True)
+        ctx.reset_accumulation(); ctx.reset_counters()
+        ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LINEAR)
+        sc = orc.OracleScene(g["prims"], g["tree"], g["cb"], near_first=near)
+        acc = np.zeros((H, W, 4), np.float32)
+        tot = dict(paths=0, rays=0, node_visits=0, box_tests=0, tri_tests=0)
+        for f in range(4):
+            c = orc.trace_frame_linear(sc, gb, f, seeds[f], acc)
+            tot = {k: tot[k] + c[k] for k in tot}
+        assert np.array_equal(_bits(ctx.linear_sum()), _bits(acc)), near
+        assert ctx.counters() == tot
+        res[near] = (acc, tot)
+    differing = np.any(res[True][0] != res[False][0], axis=-1).mean()
+    print(scene, "pixels that differ between the two orders:", differing,
+          "visits/ray", res[False][1]["node_visits"] / res[False][1]["rays"], "->", res[True][1]["node_visits"] / res[True][1]["rays"])
+    assert differing < 0.02
+    # the visit counts are close on these scenes (most visited boxes lie in front of the hit either way)
+    assert 0.8 < res[True][1]["node_visits"] / res[False][1]["node_visits"] < 1.05
+
+
+def test_build_50m_soup_properties(gpu_ctx_factory):
+    """LBVH build at 50M triangles (the larger build size of the benchmark), generated on the device.
+    Checked on the device with torch over ALL elements: codes ascending with ties in ascending primitive
+    order, a permutation, every internal box the union of its children's, parents consistent, leaves follow
+    the permutation; codes of a 200k sample against the oracle's arithmetic."""
+    import torch
+    n = 50_000_000
+    ctx = gpu_ctx_factory()
+    d = device_soup(n, seed=777)
+    ctx.upload_primitives_device(d.data_ptr(), n)
+    ctx.build()
+    bt = ctx.build_times()
+    print("50M build ms", bt)
+    codes = torch.from_numpy(ctx.morton().view(np.int64)).to("cuda")
+    perm = torch.from_numpy(ctx.permutation()).to("cuda").long()
+    ks = codes[perm]
+    assert bool(torch.all((ks[:-1] < ks[1:]) | ((ks[:-1] == ks[1:]) & (perm[:-1] < perm[1:]))))
+    seen = torch.zeros(n, dtype=torch.bool, device="cuda")
+    seen[perm] = True
+    assert bool(seen.all())
+    del seen, ks
+    # scene box and a sample of codes against the oracle's arithmetic
+    pos = d.view(n, 20)[:, [0, 1, 2, 6, 7, 8, 12, 13, 14]].reshape(n, 3, 3)
+    lo, hi = pos.min(dim=1).values, pos.max(dim=1).values
+    bb = ctx.scene_bound()
+    assert np.array_equal(bb["min"][0], lo.min(dim=0).values.cpu().numpy()) and np.array_equal(bb["max"][0], hi.max(dim=0).values.cpu().numpy())
+    sel = torch.randint(0, n, (200_000,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    sub = np.zeros(len(sel), dtype=orc.PRIM_RAY)
+    sub["bound"]["min"] = lo[sel].cpu().numpy()
+    sub["bound"]["max"] = hi[sel].cpu().numpy()
+    import ctypes as C
+    orc.lib().orc_morton_all(sub.ctypes.data_as(C.c_void_p), C.c_int(len(sel)), bb.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(sub["morton_code"].view(np.int64), codes[sel].cpu().numpy())
+    del codes
+    # the tree in the reference's layout: 100M nodes of 48 bytes, checked as 12 int32 / float32 columns
+    t = torch.from_numpy(ctx.tree().view(np.int32).reshape(2 * n, 12)).to("cuda")
+    left, right, parent, index = t[:n, 0].long(), t[:n, 1].long(), t[:, 2].long(), t[:, 3]
+    fb = t.view(torch.float32)
+    bmin, bmax = fb[:, 4:7], fb[:, 8:11]
+    ok = right < 2 * n                                       # the one node whose right child is the out-of-range leaf 2n
+    assert int((~ok).sum()) == 1
+    ar = torch.arange(n, device="cuda")
+    assert bool(torch.all(parent[left] == ar)) and bool(torch.all(parent[right[ok]] == ar[ok]))
+    assert bool(torch.all(bmin[:n][ok] == torch.minimum(bmin[left[ok]], bmin[right[ok]])))
+    assert bool(torch.all(bmax[:n][ok] == torch.maximum(bmax[left[ok]], bmax[right[ok]])))
+    assert bool(torch.all(index[n:].long() == perm))
+    assert bool(torch.all(bmin[n:] == lo[perm])) and bool(torch.all(bmax[n:] == hi[perm]))
+    # one leaf per key, every leaf reachable from exactly one parent
+    kids = torch.cat([left, right[ok]])
+    assert int(torch.unique(kids).numel()) == 2 * n - 1      # all nodes but the root
+    assert bt["sort_passes"] == 2
+    ctx.close()
+
+
+def test_render_100m_soup_properties(gpu_ctx_factory):
+    """The largest configuration at full size: 100M triangles, 3840x2160, at most 8 rays per path, full-resolution
+    codes, deep stack, nearest-child-first traversal.  Properties: every pixel received every frame, sums are
+    finite and non-negative, a second run gives the same image and the same counters bit for bit (nothing in the
+    result depends on which lane traced which path), the emitters are seen."""
+    n, W, H, frames = 100_000_000, 3840, 2160, 2
+    ctx = gpu_ctx_factory()
+    d = device_soup(n, seed=2024, scale=100.0, emitter_every=16)
+    ctx.upload_primitives_device(d.data_ptr(), n)
+    cb = soup_cb5(n, eye=CAM["eye"])
+    ctx.set_constants(cb)
+    ctx.build(ptamd.PT_BUILD_MORTON_FULL)
+    print("100M build ms", ctx.build_times())
+    ctx.resize(W, H)
+    ctx.set_stack_size(32); ctx.set_max_segments(8); ctx.set_traversal_order(ptamd.PT_TRAVERSAL_NEAR_FIRST)
+    cam = ptamd.default_camera(**CAM); cam.zfar = 1000.0
+    ctx.primary_hits(cam, ptamd.albedo_table([list(cb["mats"][0][m]["kd"][:3]) for m in range(16)]))
+    seeds = ptamd.frame_seeds(1, 0, frames)
+    runs = []
+    for _ in range(2):
+        ctx.reset_accumulation(); ctx.reset_counters()
+        ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LINEAR)
+        runs.append((ctx.linear_sum(), ctx.counters()))
+    a, c = runs[0]
+    assert np.array_equal(_bits(a), _bits(runs[1][0])) and c == runs[1][1]
+    assert np.all(a[..., 3] == frames) and np.isfinite(a).all() and np.all(a[..., :3] >= 0)
+    assert c["paths"] == W * H * frames and 0.5 * c["paths"] < c["rays"] <= 8 * c["paths"]
+    assert (a[..., :3].max(axis=-1) > 0).mean() > 0.05      # light reaches a part of the image
+    ctx.close()
+    del d

@@ -70,6 +70,73 @@ def test_raytracer_class_matches_oracle(golden, monkeypatch):
         L.pth_tracer_free(r)
 
 
+def _tracer_lib():
+    L = C.CDLL(LIB)
+    L.pth_tracer_new.restype = C.c_void_p
+    L.pth_tracer_error.restype = C.c_char_p
+    for f in ("pth_tracer_free", "pth_tracer_error", "pth_tracer_frame_count"):
+        getattr(L, f).argtypes = [C.c_void_p]
+    L.pth_tracer_load.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+    L.pth_tracer_run.argtypes = [C.c_void_p, C.c_int]
+    L.pth_tracer_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pth_tracer_set_frame_count.argtypes = [C.c_void_p, C.c_int]
+    L.pth_tracer_resize.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.pth_tracer_set_tiles.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    return L
+
+
+def _read(L, r, W, H):
+    out = np.zeros((H, W, 4), np.float32)
+    disp = np.zeros((H, W, 4), np.uint8)
+    assert L.pth_tracer_read(r, out.ctypes.data_as(C.c_void_p), disp.ctypes.data_as(C.c_void_p)) == 0, L.pth_tracer_error(r)
+    return out, disp
+
+
+def test_raytracer_resize_acc_toggle_and_tiles(golden, monkeypatch):
+    """The interactive scaffold of the reference on the facade: `resize` recreates the images and resets
+    frame_count (ray_tracer.cpp:188-261); the application's ACC toggle writes frame_count = 0 between frames
+    (CS.cpp:524-527), after which the next frame is blended with weight 0 for the old image -- no clear; the tile
+    loop (ray_tracer.cpp:298-332) with tiles_x * tiles_y dispatches per frame gives the image of one dispatch."""
+    monkeypatch.chdir(os.path.join(GOLDEN, "scenes"))
+    L = _tracer_lib()
+    g = golden["scene01"]
+    W, H = 112, 96
+    ob = orc.build(g["prims"])
+    sc = orc.OracleScene(g["prims"], ob["tree"], g["cb"])
+    kd = [list(m[0:3]) for m in g["mat_table"]] + [[0, 0, 0]] * (16 - len(g["mat_table"]))
+    alb = orc.albedo_table(g["cb"], True, kd_override=kd)
+    r = L.pth_tracer_new(0)
+    try:
+        assert L.pth_tracer_load(r, b"scene01.obj", 64, 48) == len(g["prims"]), L.pth_tracer_error(r)
+        assert L.pth_tracer_run(r, 5) == 5
+        # resize: counter back to 0, images recreated (cleared), the G-buffer is rendered again at the new size
+        assert L.pth_tracer_resize(r, W, H) == 0 and L.pth_tracer_frame_count(r) == 0
+        out, disp = _read(L, r, W, H)
+        assert not out.any() and not disp.any()
+        gb = orc.primary(sc, orc.default_camera(), W, H, alb)
+        seeds = orc.frame_seeds(1, 0, 6)
+        assert L.pth_tracer_run(r, 4) == 4, L.pth_tracer_error(r)
+        old = np.zeros((H, W, 4), np.float32)
+        for f in range(4):
+            old = orc.trace_frame(sc, gb, f, seeds[f], old)[0]
+        assert _read(L, r, W, H)[0].tobytes() == old.tobytes()
+        # ACC toggle: frame_count = 0, then one frame: framecount 0 and seed 0 again, blended over the old image with weight 0
+        L.pth_tracer_set_frame_count(r, 0)
+        assert L.pth_tracer_run(r, 1) == 1
+        old, outu, _, _ = orc.trace_frame(sc, gb, 0, seeds[0], old)
+        out, disp = _read(L, r, W, H)
+        assert out.tobytes() == old.tobytes() and np.array_equal(disp, outu)
+        # tiles: 3 x 2 dispatches per frame (112 / 3 = 37: a fourth, one-pixel column of tiles, as in the reference's loop)
+        L.pth_tracer_set_tiles(r, 3, 2)
+        assert L.pth_tracer_run(r, 2) == 3, L.pth_tracer_error(r)
+        for f in (1, 2):
+            old, outu, _, _ = orc.trace_frame(sc, gb, f, seeds[f], old)
+        out, disp = _read(L, r, W, H)
+        assert out.tobytes() == old.tobytes() and np.array_equal(disp, outu)
+    finally:
+        L.pth_tracer_free(r)
+
+
 def test_headless_driver_writes_snapshot(tmp_path):
     exe = os.path.join(ROOT, "path-tracer_amd", "host", "pt_headless")
     out = tmp_path / "snap.bmp"

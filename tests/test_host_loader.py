@@ -114,6 +114,40 @@ def test_polygon_and_material_rules(host, tmp_path, monkeypatch):
         host.pth_scene_free(s)
 
 
+@pytest.mark.parametrize("face", ["f 9999 1 2", "f 1 2 4", "f -4 1 2", "f 1//2 2//1 3//1", "f 1//-2 2//1 3//1", "f 0 1 2"])
+def test_face_indices_outside_the_arrays_are_errors(host, tmp_path, monkeypatch, face):
+    """A face may only name vertices and normals read so far: too large, forward, too negative and zero
+    indices fail the load instead of reading outside the arrays."""
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "bad.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\n" + face + "\nv 5 5 5\n")
+    assert not host.pth_scene_load(b"bad.obj")
+    (tmp_path / "good.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf -3//-1 -2//1 3//1\n")
+    s = host.pth_scene_load(b"good.obj")
+    assert s and host.pth_scene_triangle_count(s) == 1
+    host.pth_scene_free(s)
+
+
+def test_more_than_sixteen_materials_are_refused_by_the_facade(tmp_path, monkeypatch):
+    """The constant buffer holds 16 materials, the appended default one included (structs.hlsli; the
+    reference indexes past the table silently).  RayTracer::loadScene reports it instead of truncating."""
+    monkeypatch.chdir(tmp_path)
+    L = C.CDLL(LIB)
+    L.pth_tracer_new.restype = C.c_void_p
+    L.pth_tracer_error.restype = C.c_char_p
+    L.pth_tracer_error.argtypes = [C.c_void_p]
+    L.pth_tracer_free.argtypes = [C.c_void_p]
+    L.pth_tracer_load.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+    (tmp_path / "m.mtl").write_text("".join(f"newmtl m{k}\nKd 0.{k % 10} 0.5 0.5\n" for k in range(16)))
+    (tmp_path / "many.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\n" +
+                                       "".join(f"usemtl m{k}\nf 1 2 3\n" for k in range(16)))
+    r = L.pth_tracer_new(0)
+    try:
+        assert L.pth_tracer_load(r, b"many.obj", 32, 32) == -1             # 16 + the default = 17: before any GPU call
+        assert b"17 materials" in L.pth_tracer_error(r)
+    finally:
+        L.pth_tracer_free(r)
+
+
 def test_snapshot_schedule_is_the_reference_list(host):
     """CS.cpp:446-479: the frame counts at which the reference writes "<W>X<H>frame_<n>.bmp"."""
     due = [f for f in range(0, 400001) if host.pth_snapshot_due(f)]

@@ -270,12 +270,144 @@ def test_deep_tree_needs_opt_in(gpu_ctx_factory):
     assert np.array_equal(_bits(ctx.output()), _bits(old))
 
 
-def test_4k_frames_bit_exact(gpu_ctx_factory, golden):
+def test_default_stack_setting_traces_deep_trees_without_dropping(gpu_ctx_factory):
+    """pt_set_stack_size 0 (the default) is the non-dropping traversal for any tree: a 16-level tree traces
+    without any opt-in and gives the image of the reference algorithm run with a stack that never overflows."""
+    n = 40000
+    prims = make_soup(n, seed=4)
+    ctx = gpu_ctx_factory()
+    ctx.upload_primitives(prims); ctx.set_constants(soup_cb(n)); ctx.build(); ctx.resize(48, 40)
+    ctx.primary_hits(ptamd.default_camera(eye=(0.5, 0.5, 3.0), at=(0.5, 0.5, 0.5)), ptamd.albedo_table([[0.5] * 3] * 16))
+    ctx.trace(0, 9)                                        # no pt_set_stack_size call at all
+    sc = orc.OracleScene(prims, orc.build(prims)["tree"], soup_cb(n), stack_size=64)
+    old = orc.trace_frame(sc, ctx.download_gbuffer(), 0, 9, np.zeros((40, 48, 4), np.float32))[0]
+    assert np.array_equal(_bits(ctx.output()), _bits(old))
+
+
+@pytest.mark.parametrize("scene,W,H", [("scene04", 162, 118), ("scene01", 97, 61)])
+def test_region_dispatches_equal_one_full_dispatch(gpu_ctx_factory, golden, scene, W, H):
+    """pt_trace_region = one Dispatch of the reference's tile loop (ray_tracer.cpp:302-332, guard
+    ray_tracing.hlsl:402-406, bounds inclusive).  Four quadrants with the frame's seed == one pt_trace, bit
+    for bit; pixels outside a region keep their values; bounds beyond the image are clipped."""
+    ctx = gpu_ctx_factory()
+    sc, gb, _ = _setup(ctx, golden[scene], W, H)
+    seeds = ptamd.frame_seeds(1, 0, 3)
+    old = np.zeros((H, W, 4), np.float32)
+    tw, th = W // 2, H // 2                                 # odd sizes: a third, narrower column / row of tiles
+    for f in range(3):
+        prev = ctx.output().copy()
+        tiles = [(w, h) for w in range(0, W, tw) for h in range(0, H, th)]
+        for i, (w, h) in enumerate(tiles):
+            ctx.trace_region(f, seeds[f], w, h, w + tw - 1, h + th - 1)
+            if i == 0:
+                part = ctx.output()
+                assert np.array_equal(_bits(part[th:, :]), _bits(prev[th:, :])) and np.array_equal(_bits(part[:, tw:]), _bits(prev[:, tw:]))
+        old, outu, _, _ = orc.trace_frame(sc, gb, f, seeds[f], old)
+        assert np.array_equal(_bits(ctx.output()), _bits(old)), f
+        assert np.array_equal(ctx.display(), outu)
+        assert ctx.frame_count() == f + 1
+    full = gpu_ctx_factory()
+    _setup(full, golden[scene], W, H)
+    for f in range(3):
+        full.trace(f, seeds[f])
+    assert np.array_equal(_bits(full.output()), _bits(ctx.output()))
+    # an empty rectangle traces nothing; a negative offset is refused
+    before = ctx.output().copy()
+    ctx.trace_region(3, 5, W, 0, W + 10, 10)
+    assert np.array_equal(_bits(ctx.output()), _bits(before))
+    with pytest.raises(ptamd.PtError):
+        ctx.trace_region(3, 5, -1, 0, 4, 4)
+
+
+def test_material_ids_outside_the_table(gpu_ctx_factory):
+    """The constant buffer holds 16 materials.  Host uploads with another id are refused; ids that reach the
+    device unchecked (device-side primitives, G-buffer texels) read an all-zero material, never memory
+    beyond the table: library and oracle agree bit for bit."""
+    import torch
+    n, W, H = 3000, 64, 48
+    prims = make_soup(n, seed=21)
+    prims["matid"] = np.arange(n) % 4
+    bad = prims.copy()
+    bad["matid"][5] = 16
+    ctx = gpu_ctx_factory()
+    with pytest.raises(ptamd.PtError, match="material id 16"):
+        ctx.upload_primitives(bad)
+    bad["matid"][5] = -1
+    with pytest.raises(ptamd.PtError, match="material id -1"):
+        ctx.upload_primitives(bad)
+    wild = prims.copy()
+    wild["matid"][::7] = 16
+    wild["matid"][3::7] = 1 << 20
+    wild["matid"][5::7] = -3
+    d_prims = torch.from_numpy(wild.view(np.uint8).reshape(-1)).to("cuda")
+    torch.cuda.synchronize()
+    cb = soup_cb(n)
+    ctx.upload_primitives_device(d_prims.data_ptr(), n)
+    ctx.set_constants(cb); ctx.build(); ctx.resize(W, H)
+    alb = ptamd.albedo_table([list(cb["mats"][0][m]["kd"][:3]) for m in range(16)])
+    ocam = orc.default_camera(eye=(0.5, 0.5, 3.0), at=(0.5, 0.5, 0.5))
+    tree = orc.build(wild)["tree"]
+    sc = orc.OracleScene(wild, tree, cb)
+    # the G-buffer by the oracle (from the same triangles with their ids inside the table), then some
+    # texels given material words outside the table
+    gb = list(orc.primary(orc.OracleScene(prims, tree, cb), ocam, W, H, alb))
+    words = gb[1][..., 3].view(np.int32)
+    words[::5, ::3] = 17
+    words[1::5, ::3] = 0x7fffffff
+    words[2::5, ::3] = -5
+    ctx.upload_gbuffer(*gb)
+    seeds = ptamd.frame_seeds(2, 0, 3)
+    for schedule in SCHEDULES:
+        ctx.set_trace_schedule(schedule)
+        ctx.reset_accumulation()
+        ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LITERAL)
+        old = np.zeros((H, W, 4), np.float32)
+        for f in range(3):
+            old = orc.trace_frame(sc, gb, f, seeds[f], old)[0]
+        assert np.array_equal(_bits(ctx.output()), _bits(old)), schedule
+    # the ray-cast G-buffer pass with the same primitives: albedo of an id outside the table is zero
+    ctx.primary_hits(ptamd.default_camera(eye=(0.5, 0.5, 3.0), at=(0.5, 0.5, 0.5)), alb)
+    d, nn, _ = ctx.download_gbuffer()
+    ids = nn[..., 3].view(np.int32) - 1
+    out_of_table = (nn[..., 3].view(np.int32) != 0) & ((ids < 0) | (ids > 15))
+    assert out_of_table.any() and np.all(d[out_of_table][:, :3] == 0)
+
+
+def test_stream_switch_drains_the_old_stream(gpu_ctx_factory, golden):
+    """pt_set_stream between calls: work queued on the previous stream (clears, copies, build, frames) is
+    complete before anything runs on the new one, so results do not depend on where the switch falls."""
+    import torch
+    W, H = 128, 96
+    g = golden["scene01"]
+    ref = gpu_ctx_factory()
+    _setup(ref, g, W, H)
+    seeds = ptamd.frame_seeds(1, 0, 12)
+    ref.trace_frames(0, seeds, ptamd.PT_ACCUM_LITERAL)
+    want = ref.output()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    ctx = gpu_ctx_factory()
+    ctx.set_stream(s1.cuda_stream)
+    ctx.upload_primitives(g["prims"]); ctx.set_constants(g["cb"]); ctx.build()
+    ctx.set_stream(s2.cuda_stream)
+    ctx.resize(W, H)
+    ctx.set_stream(s1.cuda_stream)
+    ctx.primary_hits(ptamd.default_camera(), ptamd.albedo_table(g["mat_table"][:, 0:3], True))
+    ctx.set_trace_timing(True)
+    for k in range(4):
+        ctx.set_stream((s2 if k % 2 else s1).cuda_stream)
+        ctx.trace_frames(3 * k, seeds[3 * k:3 * k + 3], ptamd.PT_ACCUM_LITERAL)
+    ctx.set_stream(0)
+    assert np.array_equal(_bits(ctx.output()), _bits(want))
+    assert len(ctx.trace_times()) <= 1                      # pairs recorded before a switch were dropped
+
+
+@pytest.mark.parametrize("scene", ["scene02", "scene03"])
+def test_4k_frames_bit_exact(gpu_ctx_factory, golden, scene):
     """3840x2160 (the largest image of the named configurations; pixel ids beyond 2^22, which the seed
-    of ray_tracing.hlsl:410 forms in float), scene02, frames 64 and 65 in one launch: every pixel equal."""
+    of ray_tracing.hlsl:410 forms in float), scene02 and scene03, frames 64 and 65 in one launch: every pixel equal."""
     W, H = 3840, 2160
     ctx = gpu_ctx_factory()
-    sc, gb, _ = _setup(ctx, golden["scene02"], W, H)
+    sc, gb, _ = _setup(ctx, golden[scene], W, H)
     seeds = ptamd.frame_seeds(3, 64, 2)
     ctx.trace_frames(64, seeds, ptamd.PT_ACCUM_LITERAL)
     old = np.zeros((H, W, 4), np.float32)
@@ -384,6 +516,38 @@ def test_converged_image_close_to_reference_snapshot(gpu_ctx_factory, golden):
             assert rmse8 < 1.0
     assert means[True].max() < 0.3
     assert means[False].min() > 3.0
+
+
+def test_rccl_reduce_of_the_linear_sums_single_rank(gpu_ctx_factory, golden):
+    """pt_reduce_linear_sum with a one-rank RCCL communicator made through the library (ncclGetUniqueId /
+    ncclCommInitRank / ncclAllReduce / ncclCommDestroy all execute): the sums are unchanged and the resolved image
+    is the one without the reduce.  More ranks need more GPUs: the partition itself is tested with gloo on the CPU."""
+    W, H = 160, 120
+    ctx = gpu_ctx_factory()
+    sc, gb, _ = _setup(ctx, golden["scene02"], W, H)
+    with pytest.raises(ptamd.PtError, match="communicator"):
+        ctx.reduce_linear_sum()
+    seeds = ptamd.frame_seeds(1, 0, 8)
+    ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LINEAR)
+    before = ctx.linear_sum()
+    ctx.resolve()
+    want, want_u = ctx.output(), ctx.display()
+    ctx.comm_init_rank(1, 0, ptamd.unique_comm_id())
+    with pytest.raises(ptamd.PtError, match="already"):
+        ctx.comm_init_rank(1, 0, ptamd.unique_comm_id())
+    ctx.reduce_linear_sum()
+    ctx.resolve()
+    assert np.array_equal(_bits(ctx.linear_sum()), _bits(before))
+    assert np.array_equal(_bits(ctx.output()), _bits(want)) and np.array_equal(ctx.display(), want_u)
+    # a second frame block, reduced again: still the plain sum of everything traced
+    ctx.trace_frames(8, ptamd.frame_seeds(1, 8, 8), ptamd.PT_ACCUM_LINEAR)
+    ctx.reduce_linear_sum()
+    acc = np.zeros((H, W, 4), np.float32)
+    for f, s in enumerate(ptamd.frame_seeds(1, 0, 16)):
+        orc.trace_frame_linear(sc, gb, f, s, acc)
+    assert np.array_equal(_bits(ctx.linear_sum()), _bits(acc))
+    ctx.comm_destroy()
+    ctx.comm_destroy()                                      # idempotent
 
 
 def test_trace_timing_reports_one_duration_per_launch(gpu_ctx_factory, golden):
