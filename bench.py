@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config scene04|soup100m]
 
-Workload: scene04 at 1162x1008, progressive accumulation with the
-fixed-seed convention.  One STEP = one block of 128 consecutive frames (four cycles of the shader's
-frame-index stratification) = 128 paths per pixel, traced by ONE launch of the path-trace kernel
-per GPU.  The default K = 8 steps is the 1024 spp of that config.  With N GPUs every rank holds
-the scene and its tree, traces its own blocks (weak scaling), and the float accumulation sums are
-merged by one RCCL all-reduce + resolve at the end, inside the timed region.
+--config scene04 (default; the configuration the metric is quoted on): scene04 at 1162x1008, progressive
+accumulation with the fixed-seed convention.  One STEP = one block of 128 consecutive frames (four cycles of
+the shader's frame-index stratification) = 128 paths per pixel, traced by ONE launch of the path-trace kernel
+per GPU.  The default K = 8 steps is the 1024 spp of that configuration.  With N GPUs every rank holds the
+scene and its tree, traces its own blocks (weak scaling), and the float accumulation sums are merged by one
+RCCL all-reduce (pt_reduce_linear_sum, through the C ABI) + resolve at the end, inside the timed region.
+Also measured, outside the timed region: the LBVH build on 10M- and 50M-triangle random soups (per GPU,
+replicas), and a bounded CPU baseline (the oracle, rank 0, N = 1 only).
+
+--config soup100m: the largest named configuration -- a 100M-triangle random soup (generated on the device) at
+3840x2160, at most 8 rays per path, full-resolution codes, deep stack (NON-PARITY options, see include/ptamd.h).
+One STEP = one launch of 2 frames.  Node records are read from global memory: this one is bound by HBM.
 
 value = BVH traversals (`intersect()` calls, counted by the kernel) of all ranks / wall time.
-Also measured, outside the timed trace region: the LBVH build on a 10M-triangle random soup
-(per GPU, replicas), and a bounded CPU baseline (the oracle, rank 0, N = 1 only).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -26,14 +31,49 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, spec
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, data sheet
+SIMDS = 256 * 4                # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4                # maximum shader clock
+# a SIMD issues one wave64 vector instruction per 2 clocks: chip-wide peak in wave-instructions per second
+VALU_PEAK_GINST = SIMDS * CLOCK_GHZ / 2.0
+LDS_PEAK_GBS = 256 * 256 * CLOCK_GHZ          # 256 B per clock per CU
 # algorithmic bytes of the traversal model: per node visit 24 B box + 8 B children + 4 B index,
 # per triangle test three positions = 36 B
 BYTES_PER_VISIT = 36
 BYTES_PER_TRI_TEST = 36
-# build: algorithmic bytes per triangle with 15-bit codes (two 8-bit sort passes):
-# boxes+codes 72, scene box 24, sort 8 + 2*24, gather 64, links 16, refit 144
-BUILD_BYTES_PER_TRI = 376
+# build, algorithmic bytes per triangle with 15-bit codes (two 8-bit sort passes):
+# boxes+codes 72, scene box 24, sort 8 + 2*24, gather 64, links 16, refit 144 = 376 for the tree;
+# the default build also leaves the two 48-byte per-leaf records of the trace kernels: + 96
+BUILD_BYTES_TREE = 376
+BUILD_BYTES_DEFAULT = 376 + 96
+# bytes each stage's kernels request per triangle (what this implementation reads + writes, by design)
+STAGE_BYTES = {
+    "tree_only": {"bounds": 80 + 32, "morton": 32 + 4, "sort": (4 + 4 + 8) + (4 + 8 + 4), "refit": 4 + 32 + 64},
+    "default": {"bounds": 80 + 32, "morton": 32 + 4, "sort": (4 + 4 + 8) + (4 + 8 + 4), "refit": 4 + 80 + 64 + 96},
+}
+PROFILE_TRACE = os.path.join(ROOT, "profiles", "r02_trace_pmc.json")
+PROFILE_BUILD = os.path.join(ROOT, "profiles", "r02_build_pmc.json")
+KERNEL_SOURCES = ("path-tracer_amd/csrc/trace_kernels.hip", "path-tracer_amd/csrc/build_kernels.hip",
+                  "path-tracer_amd/csrc/api.hip", "path-tracer_amd/csrc/pt_internal.hpp", "include/ptamd_math.h")
+
+
+def sources_hash():
+    """Identifies the kernel sources a counter profile was taken with (the GPU box has no git history)."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_profile(path):
+    """Counter summary written by scripts/pmc_summarize.py, or None; `current` says whether it was taken with
+    the kernel sources of this tree."""
+    try:
+        p = json.load(open(path))
+    except Exception:
+        return None
+    p["_current"] = p.get("_meta", {}).get("sources_sha256_16") == sources_hash()
+    return p
 
 
 def soup(n, seed=12345):
@@ -49,6 +89,29 @@ def soup(n, seed=12345):
     prims["vertices"]["normal"][:, :, 1] = 1.0
     prims["pad"] = -1
     return prims
+
+
+def device_soup(n, seed=12345, scale=1.0, emitter_every=0):
+    """The same kind of soup generated on the GPU (no host copy), (n, 20) float32 = PrimitiveRender records;
+    materials cycle 0..3, every `emitter_every`-th triangle gets material 4."""
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    e = 0.5 * n ** (-1.0 / 3.0)
+    out = torch.zeros((n, 20), dtype=torch.float32, device="cuda")
+    c = torch.rand((n, 3), generator=g, device="cuda")
+    out[:, 0:3] = c * scale
+    out[:, 6:9] = (c + (torch.rand((n, 3), generator=g, device="cuda") * 2 - 1) * e) * scale
+    out[:, 12:15] = (c + (torch.rand((n, 3), generator=g, device="cuda") * 2 - 1) * e) * scale
+    del c
+    for k in (3, 9, 15):
+        out[:, k:k + 3] = torch.rand((n, 3), generator=g, device="cuda") * 2 - 1
+    ids = out.view(torch.int32)
+    i = torch.arange(n, device="cuda", dtype=torch.int32)
+    ids[:, 18] = torch.where(i % emitter_every == 0, torch.full_like(i, 4), i % 4) if emitter_every else i % 4
+    ids[:, 19] = -1
+    torch.cuda.synchronize()
+    return out
 
 
 class _DevArray:
@@ -76,10 +139,16 @@ def hbm_copy_gbs(nbytes=1 << 30, reps=10):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def bench_build(ctx_factory, n, reps):
+def bench_build(ctx_factory, n, reps, on_device, copy_gbs):
+    """LBVH build of an n-triangle soup, HIP events inside the library, median of `reps`.  Headline = the
+    default build (the one pt_trace* can use); the tree-only build (PT_BUILD_TREE_ONLY) is the secondary figure."""
     import ptamd
     ctx = ctx_factory()
-    ctx.upload_primitives(soup(n))
+    if on_device:
+        d = device_soup(n)
+        ctx.upload_primitives_device(d.data_ptr(), n)
+    else:
+        ctx.upload_primitives(soup(n))
 
     def median_times(flags):
         times = []
@@ -89,47 +158,58 @@ def bench_build(ctx_factory, n, reps):
         times = times[1:]
         return {k: sorted(t[k] for t in times)[len(times) // 2] for k in list(ptamd.STAGES) + ["total"]}
 
-    # the tree alone (bounds .. refit: what the 376 B/triangle model describes), and the default build,
-    # whose refit fetches the 80-byte primitives instead of the 32-byte boxes and also writes the two
-    # per-leaf records of the trace kernels
     tree = median_times(ptamd.PT_BUILD_TREE_ONLY)
     full = median_times(ptamd.PT_BUILD_DEFAULT)
     ctx.close()
-    tot, tot_all = tree.pop("total"), full.pop("total")
-    gbs = n * BUILD_BYTES_PER_TRI / (tot * 1e-3) / 1e9
-    copy_gbs = hbm_copy_gbs()
+    tot_tree, tot = tree.pop("total"), full.pop("total")
+    gbs = n * BUILD_BYTES_DEFAULT / (tot * 1e-3) / 1e9
+    gbs_tree = n * BUILD_BYTES_TREE / (tot_tree * 1e-3) / 1e9
+
+    def stage_gbs(times, model):
+        return {k: n * b / (times[k] * 1e-3) / 1e9 for k, b in model.items() if times.get(k, 0) > 0}
+
+    prof = load_profile(PROFILE_BUILD) if n == 10_000_000 else None
+    traffic = None
+    if prof and prof["_current"]:
+        per_build = {"k_bounds": 1, "k_bbox_reduce": 1, "k_morton": 1, "k_sort_hist": 2, "k_sort_scan": 2,
+                     "k_sort_scatter": 2, "k_refit_low<pack>": 1, "k_refit_upper": 2}
+        try:
+            traffic = sum(prof[k]["hbm_bytes_per_launch"] * c for k, c in per_build.items())
+        except Exception:
+            traffic = None
     return {
-        "workload": f"{n} random triangles (soup), 15-bit codes, 2 radix passes",
+        "workload": f"{n} random triangles (soup{', generated on the device' if on_device else ''}), 15-bit codes, 2 radix passes; "
+                    f"default build = tree + the trace kernels' per-leaf records",
         "mtris_per_s": n / (tot * 1e-3) / 1e6,
         "ms": tot,
-        "ms_with_trace_records": tot_all,
-        "mtris_per_s_with_trace_records": n / (tot_all * 1e-3) / 1e6,
-        "stage_ms": tree,
-        "stage_ms_with_trace_records": full,
-        "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": gbs / HBM_PEAK_GBS, "bytes_per_tri": BUILD_BYTES_PER_TRI,
-                     "traffic": build_traffic_from_profile(n),
+        "stage_ms": full,
+        "stage_GBps_requested": stage_gbs(full, STAGE_BYTES["default"]),
+        "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                     "bytes_per_tri": BUILD_BYTES_DEFAULT, "traffic": traffic,
+                     "traffic_note": None if traffic else "no counter profile taken with these kernel sources",
                      "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": gbs / copy_gbs},
+        "tree_only": {"mtris_per_s": n / (tot_tree * 1e-3) / 1e6, "ms": tot_tree, "stage_ms": tree,
+                      "stage_GBps_requested": stage_gbs(tree, STAGE_BYTES["tree_only"]),
+                      "roofline": {"bound": "hbm", "achieved": gbs_tree, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": gbs_tree / HBM_PEAK_GBS, "bytes_per_tri": BUILD_BYTES_TREE,
+                                   "frac_of_measured_copy": gbs_tree / copy_gbs},
+                      "note": "PT_BUILD_TREE_ONLY: tree and sorted order; pt_trace* refuse until a default build"},
     }
 
 
-def build_traffic_from_profile(n):
-    """HBM bytes of one build from the committed PMC summary (FETCH_SIZE doubled as the
-    gfx950 note prescribes, + WRITE_SIZE), valid for the 10M-triangle soup it was collected on."""
-    path = os.path.join(ROOT, "profiles", "r01_build_pmc.json")
-    if n != 10_000_000 or not os.path.exists(path):
-        return None
+def cpu_model():
     try:
-        p = json.load(open(path))
-        per_build = {"k_bounds": 1, "k_bbox_reduce": 1, "k_morton": 1, "k_sort_hist": 2, "k_sort_scan": 2,
-                     "k_sort_scatter": 2, "k_refit_low": 1, "k_refit_upper": 2}
-        return sum(p[k]["hbm_bytes_per_launch"] * c for k, c in per_build.items())
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
     except Exception:
-        return None
+        pass
+    return "unknown"
 
 
-def cpu_baseline(g, W, H, budget_s=12.0, max_frames=32):
-    """The oracle (CPU restatement) on this host's cores, on whole frames of the same workload."""
+def cpu_baseline(g, W, H, budget_s=10.0, max_frames=32):
+    """The oracle (CPU restatement) on this host's cores, on whole frames of the same workload: all threads
+    within a time budget, then one frame on a single thread."""
     from oracle import orc
     threads = orc.n_threads() if "ORC_THREADS" in os.environ else max(1, min(16, os.cpu_count() or 1))
     prims = g["prims"].view(orc.PRIM_RENDER)
@@ -148,9 +228,61 @@ def cpu_baseline(g, W, H, budget_s=12.0, max_frames=32):
         rays += orc.trace_frame_linear(sc, gb, frames, seeds[frames], acc, threads=threads)["rays"]
         frames += 1
     dt = time.time() - t0
+    # one thread: the top quarter of frame 0 (rows 0 .. H/4), about 1 M rays
+    sub = tuple(a[:H // 4] for a in gb)
+    acc1 = np.zeros((H // 4, W, 4), np.float32)
+    t1 = time.time()
+    rays1 = orc.trace_frame_linear(sc, sub, 0, seeds[0], acc1, threads=1)["rays"]
+    dt1 = time.time() - t1
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"scene04 {W}x{H}, frames 0..{frames - 1} ({rays} rays in {dt:.1f} s); "
+            "cpu": cpu_model(), "host_cpus": os.cpu_count(),
+            "single_thread_mrays_per_s": rays1 / dt1 / 1e6,
+            "sample": f"scene04 {W}x{H}, frames 0..{frames - 1} ({rays} rays in {dt:.1f} s on {threads} threads); one thread: "
+                      f"rows 0..{H // 4 - 1} of frame 0 ({rays1} rays in {dt1:.1f} s); "
                       f"CPU LBVH build of its {len(prims)} triangles {build_s * 1e3:.1f} ms single-threaded"}
+
+
+def trace_roofline_scene(kern_avg_ms, rays_per_launch, bytes_per_ray, launches_per_step):
+    """Roofline of k_trace_persistent with the tree in LDS.  The kernel is bound by vector-instruction issue:
+    `achieved` = vector wave-instructions per launch (hardware counter SQ_INSTS_VALU of the committed profile,
+    taken on this same launch shape) over the launch duration measured HERE with HIP events; `peak` = one wave64
+    instruction per 2 clocks per SIMD.  The algorithmic traversal bytes are served by LDS and L1/L2 and reported
+    as such, not as an HBM fraction."""
+    prof = load_profile(PROFILE_TRACE)
+    k = (prof or {}).get("k_trace_persistent")
+    on_chip = rays_per_launch * bytes_per_ray / (kern_avg_ms * 1e-3) / 1e9
+    out = {"bound": "valu", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GINST, "kernel": "k_trace_persistent",
+           "launch_ms_avg": kern_avg_ms, "launches_per_step": launches_per_step,
+           "algorithmic_bytes_served_on_chip_GBps": on_chip,
+           "peak_note": f"{SIMDS} SIMDs x {CLOCK_GHZ} GHz / 2 clocks per wave64 instruction"}
+    if not k or "SQ_INSTS_VALU" not in k:
+        out.update({"achieved": None, "frac": None, "traffic": None, "note": "no counter profile under profiles/"})
+        return out
+    valu = k["SQ_INSTS_VALU"]
+    achieved = valu / (kern_avg_ms * 1e-3) / 1e9
+    lanes = k["SQ_THREAD_CYCLES_VALU"] / valu if "SQ_THREAD_CYCLES_VALU" in k else None
+    out.update({
+        "achieved": achieved, "frac": achieved / VALU_PEAK_GINST,
+        "valu_instructions_per_launch": valu,
+        "active_lanes_per_instruction": lanes,
+        "useful_lane_frac": (achieved / VALU_PEAK_GINST) * lanes / 64.0 if lanes else None,
+        "traffic": k.get("hbm_bytes_per_launch") if prof["_current"] else None,
+        "hbm": {"bytes_per_launch": k.get("hbm_bytes_per_launch"),
+                "GBps": (k.get("hbm_bytes_per_launch", 0) / (kern_avg_ms * 1e-3) / 1e9) if k.get("hbm_bytes_per_launch") else None,
+                "peak": HBM_PEAK_GBS},
+        "profile": {"file": os.path.relpath(PROFILE_TRACE, ROOT), "taken_with_these_kernel_sources": prof["_current"],
+                    "meta": prof.get("_meta")},
+    })
+    if "SQ_INSTS_LDS" in k:
+        # every node visit is three 16-byte LDS reads per lane; conflict cycles are extra LDS-array cycles
+        lds_cycles = 4.0 * k["SQ_INSTS_LDS"] + k.get("SQ_LDS_BANK_CONFLICT", 0.0)
+        clocks = k.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        out["lds"] = {"instructions_per_launch": k["SQ_INSTS_LDS"], "bank_conflict_cycles": k.get("SQ_LDS_BANK_CONFLICT"),
+                      "array_busy_frac": (lds_cycles / 256.0 / clocks) if clocks else None,
+                      "note": "4 LDS-array cycles per ds_read_b128 wave-instruction + conflict cycles, per CU, over the launch's clocks"}
+    if not prof["_current"]:
+        out["note"] = "counter profile was taken with other kernel sources: instruction counts may be stale, traffic withheld"
+    return out
 
 
 def main():
@@ -158,13 +290,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="scene04", choices=["scene04", "soup100m"])
     ap.add_argument("--scene", default="scene04")
-    ap.add_argument("--width", type=int, default=1162)
-    ap.add_argument("--height", type=int, default=1008)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--build-tris", type=int, default=10_000_000)
+    ap.add_argument("--build-tris-large", type=int, default=50_000_000)
+    ap.add_argument("--soup-tris", type=int, default=100_000_000)
+    ap.add_argument("--soup-frames", type=int, default=2)
+    ap.add_argument("--near-first", type=int, default=0)
     ap.add_argument("--no-build", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    # a hang (a rank that never arrives at a collective) ends with every thread's stack on stderr instead of
+    # holding the GPU until somebody else's time limit
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("PTAMD_BENCH_WATCHDOG_S", "900")), exit=True)
 
     import torch
     import torch.distributed as dist
@@ -191,23 +333,78 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     stream = torch.cuda.current_stream()
+    soup_mode = args.config == "soup100m"
 
     def make_ctx():
         return ptamd.Context(local_rank, stream=stream.cuda_stream)
 
-    g = np.load(os.path.join(ROOT, "tests", "golden", args.scene + ".npz"))
-    W, H = args.width, args.height
     ctx = make_ctx()
-    ctx.upload_primitives(g["prims"].view(ptamd.PRIM_RENDER))
-    ctx.set_constants(g["cb"].view(ptamd.CB_RADIX))
-    ctx.build()
-    scene_build = ctx.build_times()
-    ctx.resize(W, H)
-    ctx.primary_hits(ptamd.default_camera(), ptamd.albedo_table(g["mat_table"][:, 0:3], True))
-    fpb = ptdist.FRAMES_PER_BLOCK
+    g = None
+    keep = None
+    if soup_mode:
+        W, H = args.width or 3840, args.height or 2160
+        n = args.soup_tris
+        keep = device_soup(n, seed=2024 + rank * 0, scale=100.0, emitter_every=16)      # every rank: the same scene
+        ctx.upload_primitives_device(keep.data_ptr(), n)
+        cb = np.zeros(1, dtype=ptamd.CB_RADIX)
+        cb["node_count"] = n
+        cb["pos"][0] = (50.0, 50.0, 300.0)
+        for k, kd in enumerate(((0.7, 0.6, 0.5), (0.3, 0.6, 0.7), (0.6, 0.7, 0.3), (0.75, 0.75, 0.75))):
+            cb["mats"][0][k]["ns"] = 1; cb["mats"][0][k]["ni"] = 1; cb["mats"][0][k]["kd"][:3] = kd
+        cb["mats"][0][4]["ke"] = 10; cb["mats"][0][4]["ns"] = 1; cb["mats"][0][4]["ni"] = 1; cb["mats"][0][4]["kd"][:3] = (1, 1, 1)
+        ctx.set_constants(cb)
+        ctx.build(ptamd.PT_BUILD_MORTON_FULL)
+        ctx.build(ptamd.PT_BUILD_MORTON_FULL)
+        scene_build = ctx.build_times()
+        ctx.resize(W, H)
+        ctx.set_stack_size(32)
+        ctx.set_max_segments(8)
+        ctx.set_traversal_order(ptamd.PT_TRAVERSAL_NEAR_FIRST if args.near_first else ptamd.PT_TRAVERSAL_REFERENCE)
+        cam = ptamd.default_camera(eye=(50.0, 50.0, 300.0), at=(50.0, 50.0, 50.0))
+        cam.zfar = 1000.0
+        ctx.primary_hits(cam, ptamd.albedo_table([list(cb["mats"][0][m]["kd"][:3]) for m in range(16)]))
+        fpb = args.soup_frames
+    else:
+        W, H = args.width or 1162, args.height or 1008
+        g = np.load(os.path.join(ROOT, "tests", "golden", args.scene + ".npz"))
+        ctx.upload_primitives(g["prims"].view(ptamd.PRIM_RENDER))
+        ctx.set_constants(g["cb"].view(ptamd.CB_RADIX))
+        ctx.build()
+        scene_build = ctx.build_times()
+        ctx.resize(W, H)
+        ctx.primary_hits(ptamd.default_camera(), ptamd.albedo_table(g["mat_table"][:, 0:3], True))
+        fpb = ptdist.FRAMES_PER_BLOCK
     ptr, nbytes = ctx.linear_sum_ptr()
     lin = torch.as_tensor(_DevArray(ptr, (H, W, 4)), device=torch.device("cuda", local_rank))
     assert lin.data_ptr() == ptr and lin.numel() * 4 == nbytes
+
+    # the merge of the accumulation sums: RCCL through the C ABI (pt_reduce_linear_sum).  The communicator's id
+    # travels over torch.distributed; if any rank cannot create its communicator all ranks agree to fall back
+    # to torch.distributed.all_reduce (the same RCCL), and the JSON line says which one ran.
+    reduce_via = "none (one GPU)"
+    if world > 1:
+        reduce_via = "torch.distributed.all_reduce"
+        if backend == "nccl":
+            ok = 1
+            try:
+                cid = [ptamd.unique_comm_id() if rank == 0 else None]
+                dist.broadcast_object_list(cid, src=0)
+                ctx.comm_init_rank(world, rank, cid[0])
+            except Exception as e:       # noqa: BLE001 -- reported below, every rank takes the same branch
+                print(f"bench.py rank {rank}: pt_comm_init_rank failed: {e}", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                reduce_via = "pt_reduce_linear_sum (ncclAllReduce through the C ABI)"
+
+    def reduce():
+        if world == 1:
+            return
+        if reduce_via.startswith("pt_reduce"):
+            ctx.reduce_linear_sum()
+        else:
+            ptdist.reduce_linear_sum(lin, dist)
 
     def step(s):
         first, cnt = ptdist.block_frames(s, rank, world, fpb)
@@ -226,6 +423,8 @@ def main():
 
     for s in range(args.warmup):
         step(s)
+    if world > 1:
+        reduce()                    # communicator warm-up outside the timed region
     ctx.reset_accumulation()
     ctx.reset_counters()
     ctx.set_trace_timing(True)      # HIP events around the trace kernel of every launch, on the library's stream
@@ -236,7 +435,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.steps):
         step(s)
-    ptdist.reduce_linear_sum(lin, dist if world > 1 else None)
+    reduce()
     ctx.resolve()
     torch.cuda.synchronize()
     if world > 1:
@@ -256,33 +455,50 @@ def main():
     assert len(kern_ms) >= args.steps and len(kern_ms) % args.steps == 0, "whole launches per step expected"
     kern_avg_ms = float(kern_ms.mean())
     rays_per_launch = cnt["rays"] / len(kern_ms)
-    achieved = rays_per_launch * bytes_per_ray / (kern_avg_ms * 1e-3) / 1e9
 
     # sanity of the result image: every pixel saw every frame of the job
     total_frames = ptdist.all_frames(args.steps, world, fpb)
     alpha = lin[..., 3]
     assert float(alpha.min().item()) == float(total_frames) == float(alpha.max().item()), "accumulation count mismatch"
 
-    build = None
-    if not args.no_build:
-        build = bench_build(make_ctx, args.build_tris, reps=5)
-        if world > 1:
-            b = torch.tensor([build["mtris_per_s"]], dtype=torch.float64, device="cuda")
-            dist.all_reduce(b, op=dist.ReduceOp.SUM)
-            build["mtris_per_s_all_gpus"] = float(b.item())
-            build["note"] = "replicas only: every GPU builds the whole soup"
-        else:
-            build["mtris_per_s_all_gpus"] = build["mtris_per_s"]
+    if soup_mode:
+        # node records and triangles come from global memory: HBM-bound; algorithmic bytes over kernel time
+        achieved = rays_per_launch * bytes_per_ray / (kern_avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None, "kernel": "k_trace_persistent (node records in global memory)",
+                    "launch_ms_avg": kern_avg_ms, "launches_per_step": len(kern_ms) // args.steps,
+                    "node_visits_per_s_G": rays_per_launch * visits_per_ray / (kern_avg_ms * 1e-3) / 1e9,
+                    "note": "algorithmic bytes = 36 B per node visit + 36 B per triangle test; a visit fetches one 64-byte "
+                            "record at a random address of a node array far larger than the caches"}
+    else:
+        roofline = trace_roofline_scene(kern_avg_ms, rays_per_launch, bytes_per_ray, len(kern_ms) // args.steps)
 
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_trace_pmc.json")
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get("k_trace_persistent", {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    builds = {}
+    if not args.no_build and not soup_mode:
+        copy_gbs = hbm_copy_gbs()
+        for key, n, on_device in (("build", args.build_tris, False), ("build_large", args.build_tris_large, True)):
+            if n <= 0:
+                continue
+            b = bench_build(make_ctx, n, 5, on_device, copy_gbs)
+            if world > 1:
+                t = torch.tensor([b["mtris_per_s"]], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                b["mtris_per_s_all_gpus"] = float(t.item())
+                b["note"] = "replicas only: every GPU builds the whole soup"
+            else:
+                b["mtris_per_s_all_gpus"] = b["mtris_per_s"]
+            builds[key] = b
 
     if rank == 0:
+        if soup_mode:
+            workload = (f"synthetic {ctx.n}-triangle soup {W}x{H}, at most 8 rays per path, {total_frames} spp "
+                        f"({args.steps} steps x {fpb} frames per GPU), full-resolution codes, deep stack, "
+                        f"{'nearest-child-first' if args.near_first else 'reference'} traversal order (NON-PARITY options)")
+            data = "soup generated on the device (torch generator seed 2024), fixed frame seeds mt19937(1), G-buffer by ray cast"
+        else:
+            workload = (f"{args.scene}.obj {W}x{H}, {total_frames} spp progressive ({args.steps} steps x {fpb} frames per GPU, "
+                        f"linear-sum accumulation, RCCL all-reduce + resolve at the end)")
+            data = f"{args.scene} fixture (reference asset), fixed seeds mt19937(1), G-buffer by ray cast"
         out = {
             "metric": "Mrays/s (whole node, scene04 1162x1008) + LBVH build Mtris/s @1/2/4/8 GPU",
             "value": rays / dt / 1e6,
@@ -295,11 +511,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": f"{args.scene} fixture (reference asset), fixed seeds mt19937(1), G-buffer by ray cast",
-            "config": {"workload": f"{args.scene}.obj {W}x{H}, {total_frames} spp progressive "
-                                   f"({args.steps} steps x {fpb} frames per GPU, linear-sum accumulation, "
-                                   f"RCCL all-reduce + resolve at the end)",
-                       "triangles": int(ctx.n), "parallelism": f"frames{world}"},
+            "data": data,
+            "config": {"workload": workload, "triangles": int(ctx.n), "parallelism": f"frames{world}", "reduce": reduce_via},
             "mpaths_per_s": paths / dt / 1e6,
             # the reference's only published figure for this path (report.md:96): another GPU, unnamed scene,
             # a different unit than the metric -- listed for orientation, not as vs_baseline
@@ -307,19 +520,13 @@ def main():
             "rays_per_path": rays / paths,
             "traversal": {"node_visits_per_ray": visits_per_ray, "tri_tests_per_ray": tris_per_ray,
                           "bytes_per_ray": bytes_per_ray},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_trace_persistent", "launch_ms_avg": kern_avg_ms,
-                         "launches_per_step": len(kern_ms) // args.steps,
-                         "note": "algorithmic bytes (36 B per node visit + 36 B per triangle test) over kernel time; "
-                                 "the node records live in LDS and the triangles in L1/L2, so these bytes never "
-                                 "reach HBM (see traffic): the kernel is bound by its per-wave instruction stream, a fraction above 1 "
-                                 "only says the tree is served on chip"},
+            "roofline": roofline,
             "scene_build_ms": scene_build["total"],
+            "scene_build_stage_ms": {k: scene_build[k] for k in ptamd.STAGES},
+            "kernel_sources_sha256_16": sources_hash(),
         }
-        if build is not None:
-            out["build"] = build
-        if world == 1 and not args.no_cpu_baseline:
+        out.update(builds)
+        if world == 1 and not args.no_cpu_baseline and not soup_mode:
             out["cpu_baseline"] = cpu_baseline(g, W, H)
         print(json.dumps(out), flush=True)
     ctx.close()

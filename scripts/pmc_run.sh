@@ -1,14 +1,15 @@
 #!/bin/bash
-# usage: pmc_run.sh <trace|build> <outdir-under-gpurun_out>
+# usage: pmc_run.sh <outdir-under-gpurun_out> <pmc_target.py arguments...>      e.g. pmc_run.sh pmc_trace trace
 # One rocprofv3 run per counter group (no trace domains mixed in), each under its own time limit.
 set -u
-MODE=$1; OUT=$GRAFT_REPO_ROOT/gpurun_out/$2
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
 run() {  # name, counters...
   local name=$1; shift
-  timeout -s KILL 150 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/scripts/pmc_target.py $MODE > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -3 $OUT/$name.log; return 1; }
+  timeout -s KILL 170 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/scripts/pmc_target.py $ARGS > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -3 $OUT/$name.log; return 1; }
   echo "pass $name ok"
 }
+ARGS="$*"
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU &&
 run sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_RD SQ_LDS_BANK_CONFLICT &&
 run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum GRBM_GUI_ACTIVE &&

@@ -1,7 +1,11 @@
 """Reads the per-pass counter CSVs of scripts/pmc_run.sh and writes a per-kernel summary (JSON + text)."""
 import csv, glob, json, os, re, sys
 from collections import defaultdict
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import sources_hash
 src, out_json = sys.argv[1], sys.argv[2]
+command = " ".join(sys.argv[3:])
 acc = defaultdict(lambda: defaultdict(float)); calls = defaultdict(lambda: defaultdict(int))
 for f in glob.glob(os.path.join(src, "*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -22,6 +26,10 @@ for k in acc:
         # i.e. reads exactly half of a wide streaming read: doubled here (upper bound for narrow gathers)
         res[k]["hbm_bytes_per_launch"] = (2.0 * res[k]["FETCH_SIZE"] + res[k]["WRITE_SIZE"]) * 1024.0
         res[k]["hbm_bytes_per_launch_uncorrected"] = (res[k]["FETCH_SIZE"] + res[k]["WRITE_SIZE"]) * 1024.0
+# which kernel sources the counters belong to (bench.py withholds figures of a profile taken with other sources)
+res["_meta"] = {"sources_sha256_16": sources_hash(), "command": command,
+                "collected_by": "scripts/pmc_run.sh: one rocprofv3 --pmc run per counter group; values are averages per launch"}
 json.dump(res, open(out_json, "w"), indent=1, sort_keys=True)
 for k in sorted(res):
-    print(k, {c: round(v, 1) for c, v in res[k].items()})
+    if k != "_meta":
+        print(k, {c: round(v, 1) for c, v in res[k].items()})

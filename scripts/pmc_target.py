@@ -1,10 +1,14 @@
-"""Small torch-free target for rocprofv3 counter passes: `trace` (scene04 1162x1008, 3 launches of
-128 frames, the benchmark's step) or `build` (10M-triangle soup, 3 tree-only builds and 3 full builds)."""
+"""Small torch-free target for rocprofv3 counter passes:
+  trace            scene04 1162x1008, 3 launches of 128 frames (the benchmark's step)
+  build [n]        n-triangle soup (default 10M), 3 tree-only builds and 3 default builds
+  soup [n] [near]  n-triangle soup (default 10M) rendered with the options of the largest configuration (full-resolution
+                   codes, deep stack, at most 8 rays per path, node records in global memory), 1920x1080, 2 launches of 2 frames"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd")); sys.path.insert(0, ROOT)
 import ptamd
+from bench import soup
 mode = sys.argv[1]
 ctx = ptamd.Context(0)
 if mode == "trace":
@@ -16,16 +20,30 @@ if mode == "trace":
         ctx.trace_frames(128 * s, ptamd.frame_seeds(1, 128 * s, 128), ptamd.PT_ACCUM_LINEAR)
     ctx.synchronize()
     print(ctx.counters())
+elif mode == "soup":
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
+    near = len(sys.argv) > 3 and sys.argv[3] == "near"
+    prims = soup(n)
+    prims["vertices"]["pos"] *= np.float32(100.0)
+    prims["matid"] = np.where(np.arange(n) % 16 == 0, 4, np.arange(n) % 4)
+    cb = np.zeros(1, dtype=ptamd.CB_RADIX)
+    cb["node_count"] = n; cb["pos"][0] = (50.0, 50.0, 300.0)
+    for k in range(4):
+        cb["mats"][0][k]["ns"] = 1; cb["mats"][0][k]["ni"] = 1; cb["mats"][0][k]["kd"][:3] = (0.7, 0.6, 0.5)
+    cb["mats"][0][4]["ke"] = 10; cb["mats"][0][4]["ns"] = 1; cb["mats"][0][4]["ni"] = 1; cb["mats"][0][4]["kd"][:3] = (1, 1, 1)
+    ctx.upload_primitives(prims); ctx.set_constants(cb); ctx.build(ptamd.PT_BUILD_MORTON_FULL)
+    ctx.set_stack_size(32); ctx.set_max_segments(8)
+    ctx.set_traversal_order(ptamd.PT_TRAVERSAL_NEAR_FIRST if near else ptamd.PT_TRAVERSAL_REFERENCE)
+    ctx.resize(1920, 1080)
+    cam = ptamd.default_camera(eye=(50.0, 50.0, 300.0), at=(50.0, 50.0, 50.0)); cam.zfar = 1000.0
+    ctx.primary_hits(cam, ptamd.albedo_table([[0.7, 0.6, 0.5]] * 16))
+    ctx.set_trace_timing(True)
+    for s in range(2):
+        ctx.trace_frames(2 * s, ptamd.frame_seeds(1, 2 * s, 2), ptamd.PT_ACCUM_LINEAR)
+    print("trace ms", ctx.trace_times(), ctx.counters())
 else:
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
-    rng = np.random.default_rng(12345)
-    c = rng.random((n, 3), dtype=np.float32); e = np.float32(0.5 * n ** (-1.0 / 3.0))
-    prims = np.zeros(n, dtype=ptamd.PRIM_RENDER)
-    prims["vertices"]["pos"][:, 0] = c
-    prims["vertices"]["pos"][:, 1] = c + (rng.random((n, 3), dtype=np.float32) * 2 - 1) * e
-    prims["vertices"]["pos"][:, 2] = c + (rng.random((n, 3), dtype=np.float32) * 2 - 1) * e
-    prims["pad"] = -1
-    ctx.upload_primitives(prims)
+    ctx.upload_primitives(soup(n))
     for flags in (ptamd.PT_BUILD_TREE_ONLY, ptamd.PT_BUILD_DEFAULT):
         for _ in range(3):
             ctx.build(flags)

@@ -4,6 +4,7 @@ partition, the all-reduce of the accumulation sums, the max-over-ranks timing an
 itself asserts that every pixel received every frame of the job."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -13,10 +14,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_bench_two_ranks_on_one_device():
     env = dict(os.environ, PTAMD_BENCH_DEVICE="0", PTAMD_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-build",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-build",
            "--width", "581", "--height", "504"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -27,3 +34,4 @@ def test_bench_two_ranks_on_one_device():
     assert d["config"]["parallelism"] == "frames2"
     assert "512 spp" in d["config"]["workload"]                # 2 ranks x 2 steps x 128 frames
     assert d["value"] > 0 and "cpu_baseline" not in d          # the CPU baseline runs at N = 1 only
+    assert d["config"]["reduce"] == "torch.distributed.all_reduce"     # gloo rehearsal; RCCL goes through pt_reduce_linear_sum
