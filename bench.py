@@ -404,7 +404,15 @@ def main():
         if reduce_via.startswith("pt_reduce"):
             ctx.reduce_linear_sum()
         else:
+            if backend != "nccl":
+                # the gloo rehearsal stages the tensor through host memory; with trace kernels still in flight on
+                # the stream its staging copy was seen never to complete (two processes on one GPU), so drain first
+                torch.cuda.synchronize()
             ptdist.reduce_linear_sum(lin, dist)
+
+    def note(msg):
+        if os.environ.get("PTAMD_BENCH_VERBOSE"):
+            print(f"[bench rank {rank} {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
     def step(s):
         first, cnt = ptdist.block_frames(s, rank, world, fpb)
@@ -421,10 +429,17 @@ def main():
     tris_per_ray = det["tri_tests"] / det["rays"]
     bytes_per_ray = visits_per_ray * BYTES_PER_VISIT + tris_per_ray * BYTES_PER_TRI_TEST
 
+    note("statistics block traced")
     for s in range(args.warmup):
         step(s)
     if world > 1:
+        torch.cuda.synchronize()
+        note("warm-up traced")
+        dist.barrier()
+        note("barrier passed")
         reduce()                    # communicator warm-up outside the timed region
+        torch.cuda.synchronize()
+        note("warm-up reduce done")
     ctx.reset_accumulation()
     ctx.reset_counters()
     ctx.set_trace_timing(True)      # HIP events around the trace kernel of every launch, on the library's stream
