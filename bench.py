@@ -298,7 +298,7 @@ def main():
     ap.add_argument("--build-tris-large", type=int, default=50_000_000)
     ap.add_argument("--soup-tris", type=int, default=100_000_000)
     ap.add_argument("--soup-frames", type=int, default=2)
-    ap.add_argument("--near-first", type=int, default=0)
+    ap.add_argument("--near-first", type=int, default=1, help="soup100m: nearest-child-first traversal order (a labelled non-parity option)")
     ap.add_argument("--no-build", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -30,6 +30,7 @@ static void read_knobs(Knobs &k)
     k.no_order = env_int("PTAMD_NO_ORDER", 0);
     k.chunk = env_int("PTAMD_CHUNK", 0);
     k.print_sched = env_int("PTAMD_PRINT_SCHED", 0);
+    k.pair_max_mib = env_int("PTAMD_PAIR_MAX_MIB", k.pair_max_mib);
 }
 
 static int bit_length_u(unsigned v) { return v ? 32 - __builtin_clz(v) : 0; }
@@ -58,6 +59,7 @@ static void free_build(pt_context *ctx)
     dev_free(ctx->d_block_hist);
     dev_free(ctx->d_tree);
     dev_free(ctx->d_wide);
+    dev_free(ctx->d_pair); ctx->pair_cap = 0; ctx->pair_valid = false;
     dev_free(ctx->d_chunk);
     dev_free(ctx->d_shade);
     dev_free(ctx->d_tri_sorted);
@@ -277,6 +279,7 @@ int pt_build(pt_context *ctx, unsigned flags)
     if (int rc = ensure_build_buffers(ctx)) return rc;
     ctx->built = false;
     ctx->tree_exported = false;
+    ctx->pair_valid = false;
     if (int rc = ptk_build(ctx, flags)) return rc;
     ctx->build_flags = flags;
     ctx->built = true;

@@ -97,6 +97,7 @@ struct Knobs {
     int no_order = 0;                   // PTAMD_NO_ORDER: image order instead of most-expensive-first
     int chunk = 0;                      // PTAMD_CHUNK: frames per work item
     int print_sched = 0;                // PTAMD_PRINT_SCHED: scheduling statistics on stderr
+    int pair_max_mib = 4096;            // PTAMD_PAIR_MAX_MIB: largest node + left-child line array (0: never use it)
 };
 
 struct pt_context {
@@ -129,6 +130,10 @@ struct pt_context {
     pt_TreeNode *d_tree = nullptr;    // 2n+1, allocated and filled by the first pt_download_tree after a build
     bool tree_exported = false;
     WideNode *d_wide = nullptr;       // n
+    float4 *d_pair = nullptr;         // 8 float4 per node (its record + its left child's), made by the first trace of a
+                                      // tree that stays in global memory
+    size_t pair_cap = 0;
+    bool pair_valid = false;
     ChunkBox *d_chunk = nullptr;      // ceil((n+1)/1024)
     float *d_root = nullptr;          // the root's own box (6 floats)
     TriShade *d_shade = nullptr;      // n+1, leaf-key order
@@ -183,7 +188,7 @@ struct pt_context {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;
     std::vector<hipEvent_t> event_pool;   // timing events waiting for reuse
     Knobs knobs;
-    int lds_attr[10] = {};             // dynamic-LDS limit already set per kernel variant (bytes)
+    int lds_attr[20] = {};             // dynamic-LDS limit already set per kernel variant (bytes)
     int near_first = 0;               // PT_TRAVERSAL_*
     unsigned char *d_scratch = nullptr;   // this device's copy of the library's static scratch array
     void *rccl_comm = nullptr;        // communicator made by pt_comm_init_rank (owned)

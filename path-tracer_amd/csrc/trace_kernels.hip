@@ -34,6 +34,7 @@ constexpr int POP = (int)0x80000000;
 
 struct SceneView {
     const WideNode *__restrict__ wide;
+    const float4 *__restrict__ pair;    // 8 float4 per internal node: its record and its left child's (k_pair_records), or null
     const TriIsect *__restrict__ tri;
     const TriShade *__restrict__ shade;
     const pt_CB_Radix *__restrict__ cb;
@@ -392,7 +393,7 @@ constexpr int K_POP = -1, K_IDLE = -2, K_NOITEM = -3;
 #endif
 constexpr int EXPANSIONS = PT_EXPANSIONS;      // node expansions per pass of the traversal loop
 
-template <bool COUNT, bool LDSN, bool NEAR>
+template <bool COUNT, bool LDSN, bool NEAR, bool PAIR = false>
 __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const TriIsect *__restrict__ tri_sorted, int levels,
                                                     unsigned n_slots,
                                                     const uint8_t *__restrict__ diffuse_tex,
@@ -464,6 +465,10 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
     bool intersected = false;
     int hit_leaf = 0;
     float hit_bx = 0, hit_by = 0, hit_bz = 0;
+    // global-memory variant: the record of the current node's left child arrived in the same 128-byte line
+    // as the node's own (next0..2); `next_valid` says that the current node IS that left child
+    float4 next0 = make_float4(0, 0, 0, 0), next1 = next0, next2 = next0;
+    bool next_valid = false;
 
     // the radiance sample of local frame fl (ray_tracing.hlsl:396-411: `multi` or black)
     auto emit = [&](const pt_f3 &color, uint32_t fl) {
@@ -605,6 +610,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                         float t_entry;
                         if (slab(root_mn, root_mx, ray.o, inv, t_entry) && t_entry <= current_t) {
                             cur_k = levels; cur_s = 0; cur_id = 0;
+                            next_valid = false;
                         }
                     }
                 }
@@ -627,9 +633,24 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                     sched[7] += __popcll(ballot64(cur_k == K_NOITEM));                     // no item (queue empty)
                 }
                 if (cur_k >= 1) {                       // only traversing lanes have cur_k >= K_POP
-                    const float4 *w = LDSN ? lds_nodes + __umul24((unsigned)cur_id, 3u)     // 24-bit multiply: full rate
-                                           : reinterpret_cast<const float4 *>(sc.wide + cur_id);
-                    const float4 w0 = w[0], w1 = w[1], w2 = w[2];
+                    float4 w0, w1, w2;
+                    if (LDSN) {
+                        const float4 *w = lds_nodes + __umul24((unsigned)cur_id, 3u);      // 24-bit multiply: full rate
+                        w0 = w[0]; w1 = w[1]; w2 = w[2];
+                    } else if (!PAIR) {
+                        const float4 *w = reinterpret_cast<const float4 *>(sc.wide + cur_id);
+                        w0 = w[0]; w1 = w[1]; w2 = w[2];
+                    } else if (next_valid) {
+                        w0 = next0; w1 = next1; w2 = next2;        // came with the parent's line: no fetch
+                    } else {
+                        // one 128-byte line: this node's record and its left child's.  The memory system serves a
+                        // random 128-byte line at the rate of a random 64-byte one, so the left descent of every
+                        // other level costs no request of its own.
+                        const float4 *w = sc.pair + (size_t)cur_id * 8;
+                        w0 = w[0]; w1 = w[1]; w2 = w[2];
+                        next0 = w[3]; next1 = w[4]; next2 = w[5];
+                    }
+                    const bool fetched_pair = PAIR && !next_valid;
                     const float lmn[3] = {w0.x, w0.y, w0.z}, lmx[3] = {w0.w, w1.x, w1.y};
                     const float rmn[3] = {w1.z, w1.w, w2.x}, rmx[3] = {w2.y, w2.z, w2.w};
                     float tl, tr;
@@ -660,6 +681,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                         cur_id = hl ? sr - 1 : sr;
                         cur_s = hl ? cur_s : sr;          // after a double miss only the bits above the pending levels matter
                     }
+                    if (PAIR) next_valid = fetched_pair && cur_k == k - 1 && cur_id == sr - 1 && k >= 2;
                 }
         };
         auto pop = [&]() {
@@ -675,6 +697,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                         const bool left = NEAR && ((pend_left >> L) & 1u);
                         if (NEAR) pend_left &= ~(1u << L);
                         if (t_entry <= current_t) {
+                            if (PAIR) next_valid = false;        // a node reached from the stack has its own line
                             const int sa = (cur_s >> L) << L, half = 1 << (L - 1);
                             const int sr = sa + half, e = min(sa + 2 * half - 1, n);
                             // a left child covers its 2^(L-1) keys fully: level L - 1, named by its last key
@@ -1272,6 +1295,37 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_intersect(SceneView sc, const
     out[i] = h;
 }
 
+// level of internal node `id` of the tree over keys 0..n (closed form: a left child is named by its last key,
+// a right child by its first key, the root is node 0)
+__device__ __forceinline__ int node_level(int id, int n, int levels)
+{
+    if (id == 0) return levels;
+    if (id & 1) return __ffs(id + 1) - 1;
+    const int e = min(id + (id & -id) - 1, n);
+    return 32 - __clz(id ^ e);
+}
+
+// One 128-byte line per internal node for the traversal of trees that live in global memory: the node's own
+// record (both child boxes, 48 bytes) followed by its LEFT child's record when that child is an internal node.
+// 8 float4 per node; float4 3..5 of a level-1 node and 6..7 of every node are unused.
+__global__ __launch_bounds__(256) void k_pair_records(const WideNode *__restrict__ wide, int n, int levels, float4 *__restrict__ pair)
+{
+    // two threads per node: thread 0 copies the node's record, thread 1 its left child's
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int id = (int)(t >> 1), half = (int)(t & 1);
+    if (id >= n) return;
+    int src = id;
+    if (half) {
+        const int k = node_level(id, n, levels);
+        if (k < 2) return;
+        const int first = (id == 0 || !(id & 1)) ? id : id - (1 << k) + 1;      // first key of the node's range
+        src = first + (1 << (k - 1)) - 1;                                       // its left child, named by its last key
+    }
+    const float4 *s = reinterpret_cast<const float4 *>(&wide[src]);
+    float4 *d = pair + (size_t)id * 8 + half * 3;
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+}
+
 __global__ void k_root_box(const WideNode *__restrict__ wide, float *__restrict__ out6)
 {   // the root's own box = union of its children's boxes (HLSL min/max)
     if (threadIdx.x < 3) {
@@ -1286,6 +1340,7 @@ __global__ void k_root_box(const WideNode *__restrict__ wide, float *__restrict_
 static int make_view(pt_context *ctx, SceneView &sv)
 {
     sv.wide = ctx->d_wide;
+    sv.pair = ctx->d_pair;
     sv.tri = ctx->d_tri_sorted;
     sv.shade = ctx->d_shade;
     sv.cb = ctx->d_cb;
@@ -1381,6 +1436,28 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
         threads = 1024;
         if (kn.max_threads >= 256) threads = (kn.max_threads / 64) * 64;
         lds_bytes = MAT_SLOTS * 64 + (size_t)levels * 4 * threads;
+    }
+    // pair lines double the node array: past a few GiB the larger footprint (address translation) costs what the
+    // saved requests gain, so the largest scenes read the plain 64-byte records
+    const size_t pair_max_nodes = kn.pair_max_mib > 0 ? ((size_t)kn.pair_max_mib << 20) / 128 : 0;
+    const bool use_pair = !lds_nodes && (size_t)ctx->n <= pair_max_nodes;
+    if (use_pair && !ctx->pair_valid) {
+        // the 128-byte node + left-child lines of the global-memory traversal, made at the first trace after a build
+        // (a build alone does not pay for them)
+        if (ctx->pair_cap < (size_t)ctx->n) {
+            PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_pair) (void)hipFree(ctx->d_pair);
+            ctx->d_pair = nullptr;
+            ctx->pair_cap = 0;
+            PT_HIP(ctx, hipMalloc((void **)&ctx->d_pair, (size_t)ctx->n * 128));
+            ctx->pair_cap = (size_t)ctx->n;
+        }
+        const long long threads2 = 2ll * ctx->n;
+        hipLaunchKernelGGL(k_pair_records, dim3((unsigned)((threads2 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_wide, ctx->n, levels,
+                           ctx->d_pair);
+        PT_HIP(ctx, hipGetLastError());
+        ctx->pair_valid = true;
+        sv.pair = ctx->d_pair;
     }
     const bool near_first = ctx->near_first != 0;
     // the wavefront schedule exists for whole-image launches in the reference's visit order
@@ -1483,10 +1560,12 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             while (frame_lanes_log2 < 8 && (2u << frame_lanes_log2) <= cnt) frame_lanes_log2++;
             hipLaunchKernelGGL(k_path_seeds, dim3((unsigned)ctx->num_cus * 16u), dim3(256), 0, ctx->stream, ctx->W, (unsigned)npix, cnt,
                                seeds, ctx->d_samples, frame_lanes_log2);
-#define PT_LAUNCH(SLOT, C, L, N) do { \
-            if (int rc_ = ensure_lds_limit(ctx, SLOT, &k_trace_persistent<C, L, N>, lds_bytes)) return rc_; \
+#define PT_LAUNCH(SLOT, C, L, N) PT_LAUNCH_(SLOT, C, L, N, false)
+#define PT_LAUNCH_G(SLOT, C, N) do { if (use_pair) PT_LAUNCH_(SLOT + 10, C, false, N, true); else PT_LAUNCH_(SLOT, C, false, N, false); } while (0)
+#define PT_LAUNCH_(SLOT, C, L, N, P) do { \
+            if (int rc_ = ensure_lds_limit(ctx, SLOT, &k_trace_persistent<C, L, N, P>, lds_bytes)) return rc_; \
             if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream)); \
-            hipLaunchKernelGGL((k_trace_persistent<C, L, N>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
+            hipLaunchKernelGGL((k_trace_persistent<C, L, N, P>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
                 n_slots, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, seeds, \
                 ctx->d_samples, ctx->d_counters, ctx->d_work, \
                 order, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, \
@@ -1494,12 +1573,14 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             // slot of the variant in ctx->lds_attr: COUNT, LDSN, NEAR as bits
             if (near_first) {
                 if (lds_nodes) { if (ctx->detailed) PT_LAUNCH(7, true, true, true); else PT_LAUNCH(6, false, true, true); }
-                else           { if (ctx->detailed) PT_LAUNCH(5, true, false, true); else PT_LAUNCH(4, false, false, true); }
+                else           { if (ctx->detailed) PT_LAUNCH_G(5, true, true); else PT_LAUNCH_G(4, false, true); }
             } else {
                 if (lds_nodes) { if (ctx->detailed) PT_LAUNCH(3, true, true, false); else PT_LAUNCH(2, false, true, false); }
-                else           { if (ctx->detailed) PT_LAUNCH(1, true, false, false); else PT_LAUNCH(0, false, false, false); }
+                else           { if (ctx->detailed) PT_LAUNCH_G(1, true, false); else PT_LAUNCH_G(0, false, false); }
             }
 #undef PT_LAUNCH
+#undef PT_LAUNCH_G
+#undef PT_LAUNCH_
             if (ev_end) PT_HIP(ctx, hipEventRecord(ev_end, ctx->stream));
             PT_HIP(ctx, hipGetLastError());
             // queue order of the next launch from the decaying per-pixel iteration counts (about
