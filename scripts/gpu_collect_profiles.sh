@@ -4,6 +4,7 @@
 #   r02_bench_default.json            the JSON line of `python bench.py` (run under the profiler: next file)
 #   r02_bench_default_kernel_stats.csv   rocprofv3 --kernel-trace --stats of that same run
 #   r02_trace_pmc.json / r02_build_pmc.json / r02_soup10m_pmc.json   hardware counters, one rocprofv3 --pmc run per group
+#   r02_bench_scene0{2,3}_4k.json     3840x2160, 512 spp per GPU (one GPU's share of the 4096 spp / 8 GPU configuration)
 #   r02_bench_soup100m*.json          the largest configuration, both traversal orders
 #   r02_random_records.txt            random record read rate of the memory system (scripts/micro/random_records.hip)
 set -u
@@ -18,7 +19,10 @@ cd /tmp && rm -rf /tmp/kstats
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kstats -- python3 $R/bench.py > $O/r02_bench_default.json 2> $O/bench_default.err || { tail -5 $O/bench_default.err; exit 1; }
 cp $(find /tmp/kstats -name '*kernel_stats.csv' | head -1) $O/r02_bench_default_kernel_stats.csv
 cd $R
-timeout -k 10 300 python3 bench.py --config soup100m --steps 3 --warmup 1 > $O/r02_bench_soup100m.json 2> $O/bench_soup.err || { tail -5 $O/bench_soup.err; exit 1; }
+for sc in scene02_4k scene03_4k; do
+  timeout -k 10 300 python3 bench.py --config $sc --steps 4 --warmup 1 --no-build --no-cpu-baseline > $O/r02_bench_$sc.json 2> $O/bench_4k.err || { tail -5 $O/bench_4k.err; exit 1; }
+done
+timeout -k 10 300 python3 bench.py --config soup100m --steps 3 --warmup 1 --near-first 0 > $O/r02_bench_soup100m.json 2> $O/bench_soup.err || { tail -5 $O/bench_soup.err; exit 1; }
 timeout -k 10 300 python3 bench.py --config soup100m --steps 3 --warmup 1 --near-first 1 > $O/r02_bench_soup100m_near_first.json 2>> $O/bench_soup.err || { tail -5 $O/bench_soup.err; exit 1; }
 ( cd scripts/micro && for cfg in "160 64 3 1024" "1280 64 3 1024" "1280 128 6 1024" "6400 64 3 1024" "12800 64 3 1024"; do timeout -k 5 60 ./random_records $cfg 1000 || exit 1; done ) > $O/r02_random_records.txt
 echo collected; ls -la $O
