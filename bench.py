@@ -498,7 +498,7 @@ def main():
     else:
         roofline = trace_roofline_scene(kern_avg_ms, rays_per_launch, bytes_per_ray, len(kern_ms) // args.steps,
                                         profile_applies=(args.scene == "scene04" and (W, H) == (1162, 1008) and
-                                                         len(kern_ms) == args.steps and world == 1))
+                                                         len(kern_ms) == args.steps))
 
     builds = {}
     if not args.no_build and not soup_mode:
