@@ -80,6 +80,15 @@ int pt_set_constants(pt_context *ctx, const pt_CB_Radix *cb);
 #define PT_BUILD_KARRAS_LINKS   4u   /* pt_download_tree also runs the search-based link kernel (the direct
                                         counterpart of radix_build_cs.hlsl) over the links it has written from
                                         the closed form of the index-keyed tree -- same values */
+#define PT_BUILD_TOPOLOGY_MORTON 16u /* NON-PARITY: the binary radix tree over the sorted Morton codes themselves (equal
+                                        codes told apart by their position; Karras 2012) instead of the reference's
+                                        tree over the leaf INDEX (radix_build_cs.hlsl:18-25 takes clz(i ^ j) of the
+                                        indices).  Splits then follow the cells of the code grid: on triangle soups
+                                        about half the node visits per ray.  n >= 2; n - 1 internal nodes, no
+                                        out-of-range leaf; trees higher than 64 levels are refused
+                                        (PT_ERR_UNSUPPORTED).  Different tree, same nearest hits: images differ from
+                                        the reference's only where two triangles are hit at equal distance.
+                                        Persistent schedule; pt_set_stack_size 0 or 32 */
 #define PT_BUILD_TREE_ONLY      8u   /* the tree and the sorted order only: the per-leaf triangle records of the
                                         trace kernels are not written (the refit then gathers the 32-byte boxes
                                         instead of the 80-byte primitives); pt_primary_hits, pt_intersect and

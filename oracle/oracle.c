@@ -13,7 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define ORC_MAX_STACK 64
+#define ORC_MAX_STACK 128
 
 /* ======================================================================= */
 /* scene flattening                                                        */
@@ -244,6 +244,40 @@ void orc_radix_tree(int n, pt_TreeNode *tree)
         do {
             t = (t + 1) >> 1;
             if (lcp(i, i + (s + t) * d, len) > sig_node) s += t;
+        } while (t > 1);
+        int gamma = i + s * d + (d < 0 ? d : 0);
+        link_node(tree, n, i, j, gamma);
+    }
+}
+
+/* NON-PARITY option, no counterpart in the reference (whose tree is keyed on the leaf index, above): the binary
+ * radix tree over the SORTED MORTON CODES themselves, equal codes told apart by their position (Karras 2012,
+ * "Maximizing parallelism in the construction of BVHs, octrees, and k-d trees", section 4).  n keys give n - 1
+ * internal nodes 0..n-2 with root 0; key k is leaf n + k; slots n-1 and 2n stay zero.  Same search loops and the
+ * same naming of children by the split position as orc_radix_tree. */
+static int lcp_codes(const uint64_t *codes, int i, int j, int n)
+{
+    if (j < 0 || j >= n) return -1;
+    uint64_t x = codes[i] ^ codes[j];
+    if (x) return __builtin_clzll(x);
+    return 64 + __builtin_clz((unsigned)(i ^ j));      /* i != j here */
+}
+void orc_radix_tree_codes(int n, const uint64_t *codes, pt_TreeNode *tree)
+{
+    for (int i = 0; i < n - 1; i++) {
+        int d = (lcp_codes(codes, i, i + 1, n) - lcp_codes(codes, i, i - 1, n) > 0) ? 1 : -1;
+        int sig_min = lcp_codes(codes, i, i - d, n);
+        int lmax = 2;
+        while (lcp_codes(codes, i, i + lmax * d, n) > sig_min) lmax *= 2;
+        int l = 0;
+        for (int t = lmax / 2; t >= 1; t /= 2)
+            if (lcp_codes(codes, i, i + (l + t) * d, n) > sig_min) l += t;
+        int j = i + l * d;
+        int sig_node = lcp_codes(codes, i, j, n);
+        int s = 0, t = l;
+        do {
+            t = (t + 1) >> 1;
+            if (lcp_codes(codes, i, i + (s + t) * d, n) > sig_node) s += t;
         } while (t > 1);
         int gamma = i + s * d + (d < 0 ? d : 0);
         link_node(tree, n, i, j, gamma);

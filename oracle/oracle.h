@@ -51,6 +51,7 @@ void     orc_strip(const pt_PrimitiveRay *rays, int n, pt_PrimitiveRayCS *out);
 /* tree has 2n+1 entries; entry 2n is the all-zero out-of-bounds node */
 void     orc_radix_tree(int n, pt_TreeNode *tree);           /* textbook loops   */
 void     orc_radix_tree_literal(int n, pt_TreeNode *tree);   /* HLSL int32 loops */
+void     orc_radix_tree_codes(int n, const uint64_t *codes, pt_TreeNode *tree);   /* NON-PARITY: keyed on the sorted codes */
 void     orc_refit(int n, const pt_PrimitiveRayCS *sorted, pt_TreeNode *tree);
 
 /* ---- RNG ------------------------------------------------------------------ */

@@ -153,6 +153,37 @@ def build_full_codes(prims):
     return {"rays": rays, "bb": bb, "sorted_rays": srt, "sorted_cs": cs, "tree": tree}
 
 
+def build_codes_topology(prims, full=False):
+    """NON-PARITY build of PT_BUILD_TOPOLOGY_MORTON: codes and order as build() (or build_full_codes() with `full`),
+    then the binary radix tree over the sorted codes (equal codes told apart by position) instead of the
+    reference's index-keyed tree: n - 1 internal nodes, slots n - 1 and 2n of the array stay zero."""
+    L = lib()
+    b = build_full_codes(prims) if full else build(prims)
+    n = len(prims)
+    assert n >= 2
+    codes = np.ascontiguousarray(b["sorted_rays"]["morton_code"])
+    tree = np.zeros(2 * n + 1, dtype=TREENODE)
+    L.orc_radix_tree_codes(C.c_int(n), _p(codes), _p(tree))
+    L.orc_refit(C.c_int(n), _p(b["sorted_cs"]), _p(tree))
+    b["tree"] = tree
+    return b
+
+
+def tree_height(tree, n):
+    """internal nodes on the longest root-to-leaf path"""
+    h = np.zeros(len(tree), dtype=np.int32)
+    order, stack = [], [0]
+    while stack:
+        i = stack.pop()
+        order.append(i)
+        for c in (int(tree["left"][i]), int(tree["right"][i])):
+            if c < n:
+                stack.append(c)
+    for i in reversed(order):
+        h[i] = 1 + max(h[tree["left"][i]], h[tree["right"][i]])
+    return int(h[0])
+
+
 def radix_tree(n, literal=False):
     tree = np.zeros(2 * n + 1, dtype=TREENODE)
     (lib().orc_radix_tree_literal if literal else lib().orc_radix_tree)(C.c_int(n), _p(tree))

@@ -60,6 +60,8 @@ static void free_build(pt_context *ctx)
     dev_free(ctx->d_tree);
     dev_free(ctx->d_wide);
     dev_free(ctx->d_pair); ctx->pair_cap = 0; ctx->pair_valid = false;
+    dev_free(ctx->d_leaf_box); ctx->leaf_box_cap = 0;
+    dev_free(ctx->d_gstack); ctx->gstack_cap = 0;
     dev_free(ctx->d_chunk);
     dev_free(ctx->d_shade);
     dev_free(ctx->d_tri_sorted);
@@ -128,7 +130,7 @@ int pt_create(int device_ordinal, pt_context **out)
     }
     if (!rc) rc = dev_alloc(ctx, &ctx->d_bbox_enc, 16);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_root, 8);
-    if (!rc) rc = dev_alloc(ctx, &ctx->d_digit_total, 8 * 256);
+    if (!rc) rc = dev_alloc(ctx, &ctx->d_digit_total, 8 * 256 + 512);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_counters, 1);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_work, 64);
     if (!rc) rc = dev_alloc(ctx, &ctx->d_wf_counts, 32 * 64 * 32);
@@ -274,9 +276,20 @@ int pt_build(pt_context *ctx, unsigned flags)
 {
     if (!ctx) return PT_ERR_INVALID;
     if (!ctx->d_prims || ctx->n < 1) PT_FAIL(ctx, PT_ERR_INVALID, "pt_build: no primitives uploaded");
-    if (flags & ~(PT_BUILD_MORTON_FULL | PT_BUILD_KARRAS_LINKS | PT_BUILD_TREE_ONLY)) PT_FAIL(ctx, PT_ERR_INVALID, "pt_build: unknown flag");
+    if (flags & ~(PT_BUILD_MORTON_FULL | PT_BUILD_KARRAS_LINKS | PT_BUILD_TREE_ONLY | PT_BUILD_TOPOLOGY_MORTON))
+        PT_FAIL(ctx, PT_ERR_INVALID, "pt_build: unknown flag");
+    if ((flags & PT_BUILD_TOPOLOGY_MORTON) && (flags & PT_BUILD_KARRAS_LINKS))
+        PT_FAIL(ctx, PT_ERR_INVALID, "pt_build: PT_BUILD_KARRAS_LINKS belongs to the index-keyed tree");
+    if ((flags & PT_BUILD_TOPOLOGY_MORTON) && ctx->n < 2) PT_FAIL(ctx, PT_ERR_UNSUPPORTED, "pt_build: PT_BUILD_TOPOLOGY_MORTON needs n >= 2");
     if (int rc = set_device(ctx)) return rc;
     if (int rc = ensure_build_buffers(ctx)) return rc;
+    if ((flags & PT_BUILD_TOPOLOGY_MORTON) && ctx->leaf_box_cap < (size_t)ctx->n) {
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        dev_free(ctx->d_leaf_box);
+        ctx->leaf_box_cap = 0;
+        if (int rc = dev_alloc(ctx, &ctx->d_leaf_box, 2 * (size_t)ctx->capacity)) return rc;
+        ctx->leaf_box_cap = (size_t)ctx->capacity;
+    }
     ctx->built = false;
     ctx->tree_exported = false;
     ctx->pair_valid = false;
@@ -523,6 +536,8 @@ static int check_trace_ready(pt_context *ctx, const char *who)
     // The reference's 15-entry stack silently drops subtrees of trees deeper than 13 levels; this
     // library never drops.  stack_entries 15 is the strict-parity guard (deep trees are refused); 0, the
     // default, and 32 trace any tree with the non-dropping traversal.
+    if (ctx->stack_entries == 15 && (ctx->build_flags & PT_BUILD_TOPOLOGY_MORTON))
+        PT_FAIL(ctx, PT_ERR_UNSUPPORTED, std::string(who) + ": the strict-parity stack (15) does not go with PT_BUILD_TOPOLOGY_MORTON");
     if (ctx->stack_entries == 15 && bit_length_u((unsigned)ctx->n) > 14)
         PT_FAIL(ctx, PT_ERR_UNSUPPORTED, std::string(who) + ": tree deeper than the 15-entry reference stack; pt_set_stack_size(ctx, 32)");
     return PT_OK;

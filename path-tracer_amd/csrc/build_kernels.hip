@@ -11,6 +11,8 @@
 // must not be fused).
 #include "pt_internal.hpp"
 
+#include <algorithm>
+
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -601,16 +603,190 @@ __global__ __launch_bounds__(256) void k_cost_keys(uint32_t *__restrict__ cost, 
     keys[i] = 65535u - (c > 65535u ? 65535u : c);
 }
 
+// ---------------------------------------------------------------------------
+// NON-PARITY option PT_BUILD_TOPOLOGY_MORTON (no counterpart in the reference, whose tree is keyed
+// on the leaf index): the binary radix tree over the SORTED CODES, equal codes told apart by their
+// position (Karras 2012, section 4).  n keys give n - 1 internal nodes, root 0; children are named
+// by the split position as everywhere else (left = gamma, right = gamma + 1, leaves as ~key).
+//
+// Boxes bottom-up without any inter-workgroup hand-off: a child's common prefix is strictly longer
+// than its parent's, so the nodes are bucketed by prefix length (one stable 8-bit counting pass of the
+// radix sort over the n - 1 lengths) and the buckets are processed longest prefix first, one launch per
+// length.  A node reads its children's records (their two boxes give the child's own box) or the
+// leaf boxes, and writes its record once.
+// ---------------------------------------------------------------------------
+template <typename K>
+__device__ __forceinline__ int lcp_codes(const K *__restrict__ codes, K ci, int i, int j, int n)
+{
+    if (j < 0 || j >= n) return -1;
+    const K x = ci ^ codes[j];
+    if (x != 0) return sizeof(K) == 8 ? __clzll((unsigned long long)x) : __clz((unsigned)x);
+    return 8 * (int)sizeof(K) + __clz(i ^ j);          // i != j here
+}
+
+template <typename K>
+__global__ __launch_bounds__(256) void k_karras_codes(const K *__restrict__ codes, int n, WideNode *__restrict__ wide,
+                                                      uint32_t *__restrict__ prefix_len)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n - 1) return;
+    const K ci = codes[i];
+    const int d = (lcp_codes(codes, ci, i, i + 1, n) - lcp_codes(codes, ci, i, i - 1, n) > 0) ? 1 : -1;
+    const int sig_min = lcp_codes(codes, ci, i, i - d, n);
+    int lmax = 2;
+    while (lcp_codes(codes, ci, i, i + lmax * d, n) > sig_min) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (lcp_codes(codes, ci, i, i + (l + t) * d, n) > sig_min) l += t;
+    const int j = i + l * d;
+    const int sig_node = lcp_codes(codes, ci, i, j, n);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (lcp_codes(codes, ci, i, i + (s + t) * d, n) > sig_node) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + min(d, 0);
+    const int left = (min(i, j) == gamma) ? ~gamma : gamma;
+    const int right = (max(i, j) == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+    reinterpret_cast<float4 *>(&wide[i])[3] = make_float4(__int_as_float(left), __int_as_float(right), 0.0f, 0.0f);
+    prefix_len[i] = (uint32_t)sig_node;
+}
+
+// the leaf half of k_refit_low for the Morton-keyed tree: one key per lane, the box in leaf order
+// (two float4 per key: min.xyz, max.xyz) and, with PACK, the two per-leaf records of the trace kernels
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_leaf_records(const uint32_t *__restrict__ perm, const BoxRec *__restrict__ boxes,
+                                                      const uint4 *__restrict__ prims16, int n, float4 *__restrict__ leaf_box,
+                                                      TriIsect *__restrict__ tri, TriShade *__restrict__ shade)
+{
+    const int key = blockIdx.x * 256 + threadIdx.x;
+    if (key >= n) return;
+    const int p = (int)perm[key];
+    float b[6];
+    if (PACK) {
+        const float4 *src = reinterpret_cast<const float4 *>(prims16 + (size_t)p * (PRIM_DW / 4));
+        const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
+        const float A[3] = {v0.x, v0.y, v0.z}, B[3] = {v1.z, v1.w, v2.x}, C[3] = {v3.x, v3.y, v3.z};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            // math3d.h:13-23, as in k_bounds
+            const float x = A[k], y = B[k], z = C[k];
+            const float yz_max = (y > z) ? y : z, yz_min = (y < z) ? y : z;
+            b[3 + k] = (x > yz_max) ? x : yz_max;
+            b[k] = (x < yz_min) ? x : yz_min;
+        }
+        float4 *td = reinterpret_cast<float4 *>(&tri[key]);
+        td[0] = make_float4(A[0], A[1], A[2], __int_as_float(p));
+        td[1] = make_float4(B[0] - A[0], B[1] - A[1], B[2] - A[2], 0.0f);
+        td[2] = make_float4(C[0] - A[0], C[1] - A[1], C[2] - A[2], 0.0f);
+        float4 *sd = reinterpret_cast<float4 *>(&shade[key]);
+        sd[0] = make_float4(v0.w, v1.x, v1.y, v4.z);
+        sd[1] = make_float4(v2.y, v2.z, v2.w, 0.0f);
+        sd[2] = make_float4(v3.w, v4.x, v4.y, 0.0f);
+    } else {
+        const float4 *src = reinterpret_cast<const float4 *>(&boxes[p]);
+        const float4 lo = src[0], hi = src[1];
+        b[0] = lo.x; b[1] = lo.y; b[2] = lo.z; b[3] = hi.x; b[4] = hi.y; b[5] = hi.z;
+    }
+    leaf_box[2 * (size_t)key] = make_float4(b[0], b[1], b[2], 0.0f);
+    leaf_box[2 * (size_t)key + 1] = make_float4(b[3], b[4], b[5], 0.0f);
+}
+
+// exclusive prefix of the 256 bucket sizes (one workgroup)
+__global__ __launch_bounds__(256) void k_level_offsets(const uint32_t *__restrict__ digit_total, uint32_t *__restrict__ level_off)
+{
+    __shared__ uint32_t sh[5];
+    uint32_t total;
+    const uint32_t ex = block_excl_scan_256(digit_total[threadIdx.x], sh, &total);
+    level_off[threadIdx.x] = ex;
+    if (threadIdx.x == 255) level_off[256] = total;
+}
+
+// box and height of child `c` of a node of the Morton-keyed tree
+__device__ __forceinline__ void gen_child_box(int c, const WideNode *__restrict__ wide, const float4 *__restrict__ leaf_box,
+                                              float *B, int &height)
+{
+    if (c >= 0) {
+        const float4 *w = reinterpret_cast<const float4 *>(&wide[c]);
+        const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+        B[0] = fminf(w0.x, w1.z); B[1] = fminf(w0.y, w1.w); B[2] = fminf(w0.z, w2.x);
+        B[3] = fmaxf(w0.w, w2.y); B[4] = fmaxf(w1.x, w2.z); B[5] = fmaxf(w1.y, w2.w);
+        height = __float_as_int(w3.z);
+    } else {
+        const float4 lo = leaf_box[2 * (size_t)~c], hi = leaf_box[2 * (size_t)~c + 1];
+        B[0] = lo.x; B[1] = lo.y; B[2] = lo.z; B[3] = hi.x; B[4] = hi.y; B[5] = hi.z;
+        height = 0;
+    }
+}
+
+// the nodes whose prefix length is `level`: nodes[level_off[level] .. level_off[level + 1])
+__global__ __launch_bounds__(256) void k_refit_level(int level, const uint32_t *__restrict__ level_off,
+                                                     const uint32_t *__restrict__ nodes, WideNode *__restrict__ wide,
+                                                     const float4 *__restrict__ leaf_box)
+{
+    const uint32_t begin = level_off[level], end = level_off[level + 1];
+    for (uint32_t idx = begin + blockIdx.x * 256u + threadIdx.x; idx < end; idx += gridDim.x * 256u) {
+        const int node = (int)nodes[idx];
+        const float4 ids = reinterpret_cast<const float4 *>(&wide[node])[3];
+        const int left = __float_as_int(ids.x), right = __float_as_int(ids.y);
+        float L[6], R[6];
+        int hl, hr;
+        gen_child_box(left, wide, leaf_box, L, hl);
+        gen_child_box(right, wide, leaf_box, R, hr);
+        float4 *dst = reinterpret_cast<float4 *>(&wide[node]);
+        dst[0] = make_float4(L[0], L[1], L[2], L[3]);
+        dst[1] = make_float4(L[4], L[5], R[0], R[1]);
+        dst[2] = make_float4(R[2], R[3], R[4], R[5]);
+        dst[3] = make_float4(ids.x, ids.y, __int_as_float(1 + max(hl, hr)), 0.0f);     // height: levels below the node
+    }
+}
+
+// reference-layout export of the Morton-keyed tree: records first (parent 0), then the parents
+__global__ __launch_bounds__(256) void k_export_leaves_codes(const uint32_t *__restrict__ perm, const BoxRec *__restrict__ boxes,
+                                                             int n, pt_TreeNode *__restrict__ tree)
+{
+    const int key = blockIdx.x * 256 + threadIdx.x;
+    if (key >= n) return;
+    const int p = (int)perm[key];
+    const float4 *src = reinterpret_cast<const float4 *>(&boxes[p]);
+    const float4 lo = src[0], hi = src[1];
+    const float b[6] = {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z};
+    write_tree_node(&tree[(long long)n + key], 0, 0, 0, p, b);
+}
+__global__ __launch_bounds__(256) void k_export_nodes_codes(int n, const WideNode *__restrict__ wide, pt_TreeNode *__restrict__ tree)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n - 1) return;
+    const float4 *w = reinterpret_cast<const float4 *>(&wide[i]);
+    const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+    const float L[6] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y}, R[6] = {w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+    float U[6];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { U[c] = fminf(L[c], R[c]); U[3 + c] = fmaxf(L[3 + c], R[3 + c]); }
+    const int left = __float_as_int(w3.x), right = __float_as_int(w3.y);
+    write_tree_node(&tree[i], left < 0 ? n + ~left : left, right < 0 ? n + ~right : right, 0, 0, U);
+}
+__global__ __launch_bounds__(256) void k_export_parents_codes(int n, const WideNode *__restrict__ wide, pt_TreeNode *__restrict__ tree)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n - 1) return;
+    const float4 w3 = reinterpret_cast<const float4 *>(&wide[i])[3];
+    const int left = __float_as_int(w3.x), right = __float_as_int(w3.y);
+    tree[left < 0 ? n + ~left : left].parent = i;
+    tree[right < 0 ? n + ~right : right].parent = i;
+}
+
 inline int bit_length(unsigned v) { return v ? 32 - __builtin_clz(v) : 0; }
 
 }  // namespace
 
 // `passes` stable 8-bit passes over `keys` (n keys; values start as 0..n-1).  The passes
 // ping-pong between kbuf/vbuf [0] and [1]; returns the index of the vbuf that holds the
-// permutation.  The sorted keys themselves are not produced by the last pass.
+// permutation.  The sorted keys themselves are produced by the last pass only with `keys_last`
+// (into the kbuf of the same index).
 template <typename K>
 static int radix_sort_passes(hipStream_t st, const K *keys, int n, int passes, K *const kbuf[2], uint32_t *const vbuf[2],
-                             uint32_t *block_hist, uint32_t *digit_total)
+                             uint32_t *block_hist, uint32_t *digit_total, bool keys_last = false)
 {
     const int nblocks = (n + PT_SORT_TILE - 1) / PT_SORT_TILE;
     const K *kin = keys;
@@ -619,7 +795,7 @@ static int radix_sort_passes(hipStream_t st, const K *keys, int n, int passes, K
     for (int p = 0; p < passes; p++) {
         const int shift = 8 * p;
         uint32_t *dtot = digit_total + 256 * p;
-        const bool first = (p == 0), last = (p == passes - 1);
+        const bool first = (p == 0), last = (p == passes - 1) && !keys_last;
         hipLaunchKernelGGL(k_sort_hist<K>, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, n, shift, block_hist, nblocks);
         hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, st, block_hist, dtot, nblocks);
 #define PT_SCATTER(I, KO) hipLaunchKernelGGL((k_sort_scatter<K, I, KO>), dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, vin, \
@@ -681,16 +857,50 @@ static int run_build(pt_context *ctx, const BuildBufs &b, const uint4 *prims16, 
     // 15 bits: two 8-bit passes sort them completely.  Full-resolution codes
     // have 63 bits: eight passes.
     const int passes = full ? 8 : 2;
+    const bool by_codes = (flags & PT_BUILD_TOPOLOGY_MORTON) != 0;      // the tree search reads the sorted codes
     if (full) {
         uint64_t *const kb[2] = {static_cast<uint64_t *>(b.keys[0]), static_cast<uint64_t *>(b.keys[1])};
         *sorted_buf = radix_sort_passes<uint64_t>(st, static_cast<const uint64_t *>(b.morton), n, passes, kb, b.vals,
-                                                  b.block_hist, b.digit_total);
+                                                  b.block_hist, b.digit_total, by_codes);
     } else {
         uint32_t *const kb[2] = {static_cast<uint32_t *>(b.keys[0]), static_cast<uint32_t *>(b.keys[1])};
         *sorted_buf = radix_sort_passes<uint32_t>(st, static_cast<const uint32_t *>(b.morton), n, passes, kb, b.vals,
-                                                  b.block_hist, b.digit_total);
+                                                  b.block_hist, b.digit_total, by_codes);
     }
     if (ev) PT_HIP(ctx, hipEventRecord(ev[PT_STAGE_SORT + 1], st));
+
+    if (by_codes) {
+        // NON-PARITY topology: links by search over the sorted codes, nodes bucketed by prefix length (one
+        // counting pass of the sort over the n - 1 lengths), boxes bucket by bucket from the longest prefix up
+        const int sb = *sorted_buf, other = sb ^ 1;
+        const uint32_t *perm = b.vals[sb];
+        uint32_t *prefix_len = static_cast<uint32_t *>(b.keys[other]);   // the ping-pong half the sort left free
+        uint32_t *nodes = b.vals[other];
+        uint32_t *level_off = b.digit_total + 8 * 256;
+        const int grid_i = (n - 1 + 255) / 256;
+        if (full) hipLaunchKernelGGL(k_karras_codes<uint64_t>, dim3(grid_i), dim3(256), 0, st, static_cast<const uint64_t *>(b.keys[sb]), n,
+                                     b.wide, prefix_len);
+        else      hipLaunchKernelGGL(k_karras_codes<uint32_t>, dim3(grid_i), dim3(256), 0, st, static_cast<const uint32_t *>(b.keys[sb]), n,
+                                     b.wide, prefix_len);
+        {
+            uint32_t *const kb[2] = {nullptr, nullptr};
+            uint32_t *const vb[2] = {nodes, nullptr};
+            (void)radix_sort_passes<uint32_t>(st, prefix_len, n - 1, 1, kb, vb, b.block_hist, b.digit_total);
+            hipLaunchKernelGGL(k_level_offsets, dim3(1), dim3(256), 0, st, b.digit_total, level_off);
+        }
+        if (ev) PT_HIP(ctx, hipEventRecord(ev[PT_STAGE_TOPOLOGY + 1], st));
+        if (flags & PT_BUILD_TREE_ONLY)
+            hipLaunchKernelGGL(k_leaf_records<false>, dim3(grid_n), dim3(256), 0, st, perm, b.boxes, prims16, n, b.leaf_box, b.tri, b.shade);
+        else
+            hipLaunchKernelGGL(k_leaf_records<true>, dim3(grid_n), dim3(256), 0, st, perm, b.boxes, prims16, n, b.leaf_box, b.tri, b.shade);
+        const int longest = (full ? 64 : 32) + 31;           // code bits + the position bits that separate equal codes
+        const unsigned level_grid = (unsigned)std::min(grid_i, 8 * ctx->num_cus);
+        for (int level = longest; level >= 0; level--)
+            hipLaunchKernelGGL(k_refit_level, dim3(level_grid), dim3(256), 0, st, level, level_off, nodes, b.wide, b.leaf_box);
+        if (ev) PT_HIP(ctx, hipEventRecord(ev[PT_STAGE_REFIT + 1], st));
+        PT_HIP(ctx, hipGetLastError());
+        return PT_OK;
+    }
 
     // The topology of the index-keyed tree is a closed form of n (see the refit kernels): the
     // refit writes child ids from it, and nothing else has to run for this stage.
@@ -732,10 +942,22 @@ int ptk_build(pt_context *ctx, unsigned flags)
     b.vals[0] = ctx->d_vals[0]; b.vals[1] = ctx->d_vals[1];
     b.morton = ctx->d_morton; b.block_hist = ctx->d_block_hist; b.digit_total = ctx->d_digit_total;
     b.wide = ctx->d_wide; b.chunk = ctx->d_chunk; b.shade = ctx->d_shade; b.tri = ctx->d_tri_sorted;
+    b.leaf_box = ctx->d_leaf_box;
     const bool full = (flags & PT_BUILD_MORTON_FULL) != 0;
     if (int rc = run_build(ctx, b, reinterpret_cast<const uint4 *>(ctx->d_prims), ctx->n, flags, ctx->ev, &ctx->sorted_buf)) return rc;
     ctx->morton_bits = full ? 64 : 32;
     ctx->sort_passes = full ? 8 : 2;
+    ctx->tree_height = 0;
+    if (flags & PT_BUILD_TOPOLOGY_MORTON) {
+        // the traversal stacks are sized by the height of the tree, which only the finished tree tells
+        int h = 0;
+        PT_HIP(ctx, hipMemcpyAsync(&h, &ctx->d_wide[0].pad[0], sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (h < 1 || h > PT_MAX_TREE_HEIGHT)
+            PT_FAIL(ctx, PT_ERR_UNSUPPORTED, "pt_build: PT_BUILD_TOPOLOGY_MORTON gave a tree of height " + std::to_string(h) +
+                    " (limit " + std::to_string(PT_MAX_TREE_HEIGHT) + "); build without the flag");
+        ctx->tree_height = h;
+    }
     // the per-leaf records of the trace kernels were written by the refit (unless PT_BUILD_TREE_ONLY); what
     // is left is the root's own box
     if (int rc = ptk_root_box(ctx)) return rc;
@@ -848,6 +1070,15 @@ int ptk_export_tree(pt_context *ctx)
     const int n = ctx->n;
     hipStream_t st = ctx->stream;
     const int top = bit_length((unsigned)n);
+    if (ctx->build_flags & PT_BUILD_TOPOLOGY_MORTON) {
+        // n - 1 internal nodes: slots n - 1 and 2n stay zero
+        PT_HIP(ctx, hipMemsetAsync(ctx->d_tree, 0, (2 * (size_t)n + 1) * sizeof(pt_TreeNode), st));
+        hipLaunchKernelGGL(k_export_leaves_codes, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_vals[ctx->sorted_buf], ctx->d_boxes, n, ctx->d_tree);
+        hipLaunchKernelGGL(k_export_nodes_codes, dim3((n + 254) / 256), dim3(256), 0, st, n, ctx->d_wide, ctx->d_tree);
+        hipLaunchKernelGGL(k_export_parents_codes, dim3((n + 254) / 256), dim3(256), 0, st, n, ctx->d_wide, ctx->d_tree);
+        PT_HIP(ctx, hipGetLastError());
+        return PT_OK;
+    }
     PT_HIP(ctx, hipMemsetAsync(&ctx->d_tree[2 * (size_t)n], 0, sizeof(pt_TreeNode), st));
     hipLaunchKernelGGL(k_export_leaves, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_vals[ctx->sorted_buf], ctx->d_boxes, n, ctx->d_tree);
     const long long nb1 = ((long long)n + 2) >> 1;        // blocks of level 1, the widest level

@@ -66,6 +66,8 @@ constexpr int PT_REFIT_CHUNK_LOG2 = 10;
 constexpr int PT_REFIT_CHUNK = 1 << PT_REFIT_CHUNK_LOG2;        // 1024 sorted keys per workgroup
 
 constexpr int PT_SEED_SLOTS = 4;
+// highest Morton-keyed tree the traversal stacks are sized for (PT_BUILD_TOPOLOGY_MORTON)
+constexpr int PT_MAX_TREE_HEIGHT = 64;
 // size of the library's static scratch array (pt_build_tree_noalloc): what PT_NOALLOC_MAX_PRIMS needs
 constexpr size_t PT_NOALLOC_SCRATCH_BYTES = (size_t)14 << 20;
 
@@ -79,7 +81,8 @@ struct BuildBufs {
     uint32_t *vals[2] = {nullptr, nullptr};
     void *morton = nullptr;             // n codes in primitive order, 4 or 8 bytes each
     uint32_t *block_hist = nullptr;     // 256 per PT_SORT_TILE keys
-    uint32_t *digit_total = nullptr;    // 8 * 256
+    uint32_t *digit_total = nullptr;    // 8 * 256, followed by 512 words for the bucket offsets of PT_BUILD_TOPOLOGY_MORTON
+    float4 *leaf_box = nullptr;         // PT_BUILD_TOPOLOGY_MORTON only: 2 per key (min.xyz, max.xyz in leaf order)
     WideNode *wide = nullptr;           // n
     ChunkBox *chunk = nullptr;          // per 1024 keys, plus the upper levels' groups
     TriShade *shade = nullptr;          // n + 1 (unused with PT_BUILD_TREE_ONLY)
@@ -126,7 +129,12 @@ struct pt_context {
     int morton_bits = 64;
     int sorted_buf = 0;               // which of d_keys/d_vals holds the sorted result
     uint32_t *d_block_hist = nullptr; // 256 * nblocks
-    uint32_t *d_digit_total = nullptr;// 8 * 256
+    uint32_t *d_digit_total = nullptr;// 8 * 256 + 512
+    float4 *d_leaf_box = nullptr;     // 2 per key, allocated by the first PT_BUILD_TOPOLOGY_MORTON build
+    size_t leaf_box_cap = 0;
+    int tree_height = 0;              // PT_BUILD_TOPOLOGY_MORTON: internal nodes on the longest root-to-leaf path
+    uint2 *d_gstack = nullptr;        // traversal-stack entries beyond the LDS part (Morton-keyed trees deeper than that)
+    size_t gstack_cap = 0;            // entries
     pt_TreeNode *d_tree = nullptr;    // 2n+1, allocated and filled by the first pt_download_tree after a build
     bool tree_exported = false;
     WideNode *d_wide = nullptr;       // n
@@ -188,7 +196,7 @@ struct pt_context {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;
     std::vector<hipEvent_t> event_pool;   // timing events waiting for reuse
     Knobs knobs;
-    int lds_attr[20] = {};             // dynamic-LDS limit already set per kernel variant (bytes)
+    int lds_attr[32] = {};             // dynamic-LDS limit already set per kernel variant (bytes)
     int near_first = 0;               // PT_TRAVERSAL_*
     unsigned char *d_scratch = nullptr;   // this device's copy of the library's static scratch array
     void *rccl_comm = nullptr;        // communicator made by pt_comm_init_rank (owned)

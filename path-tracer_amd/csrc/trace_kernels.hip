@@ -393,8 +393,12 @@ constexpr int K_POP = -1, K_IDLE = -2, K_NOITEM = -3;
 #endif
 constexpr int EXPANSIONS = PT_EXPANSIONS;      // node expansions per pass of the traversal loop
 
-template <bool COUNT, bool LDSN, bool NEAR, bool PAIR = false>
+// GEN: the tree has explicit child ids (PT_BUILD_TOPOLOGY_MORTON: no closed form) and an explicit per-lane stack
+// of (node, entry distance) pairs: `levels` then is the number of stack entries held in LDS, deeper entries go to
+// `gstack` (entry e of lane L of workgroup B at gstack[(e - levels) * lanes_total + B * blockDim + L]).
+template <bool COUNT, bool LDSN, bool NEAR, bool PAIR = false, bool GEN = false>
 __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const TriIsect *__restrict__ tri_sorted, int levels,
+                                                    uint2 *__restrict__ gstack,
                                                     unsigned n_slots,
                                                     const uint8_t *__restrict__ diffuse_tex,
                                                     const float4 *__restrict__ normal_tex,
@@ -469,6 +473,11 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
     // as the node's own (next0..2); `next_valid` says that the current node IS that left child
     float4 next0 = make_float4(0, 0, 0, 0), next1 = next0, next2 = next0;
     bool next_valid = false;
+    int next_l = 0, next_r = 0;         // GEN + PAIR: the left child's own child ids
+    // GEN: `pending` counts the stack entries; the deeper part of the stack of this lane
+    uint2 *const gst = GEN ? gstack + ((size_t)blockIdx.x * nthreads + threadIdx.x) : nullptr;
+    const size_t gstride = GEN ? (size_t)gridDim.x * nthreads : 0;
+    float *const stack_t = stack + (GEN ? (size_t)levels * nthreads : 0);       // GEN: ids first, then the distances
 
     // the radiance sample of local frame fl (ray_tracing.hlsl:396-411: `multi` or black)
     auto emit = [&](const pt_f3 &color, uint32_t fl) {
@@ -609,7 +618,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                         if (COUNT) { cnt.node_visits++; cnt.box_tests++; }
                         float t_entry;
                         if (slab(root_mn, root_mx, ray.o, inv, t_entry) && t_entry <= current_t) {
-                            cur_k = levels; cur_s = 0; cur_id = 0;
+                            cur_k = GEN ? 1 : levels; cur_s = 0; cur_id = 0;
                             next_valid = false;
                         }
                     }
@@ -632,6 +641,53 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                     sched[6] += __popcll(ballot64(cur_k == K_IDLE));                       // waiting for a refill
                     sched[7] += __popcll(ballot64(cur_k == K_NOITEM));                     // no item (queue empty)
                 }
+                if (GEN) {
+                    if (cur_k >= 1) {
+                        float4 w0, w1, w2;
+                        int left, right;
+                        if (!PAIR) {
+                            const float4 *w = reinterpret_cast<const float4 *>(sc.wide + cur_id);
+                            w0 = w[0]; w1 = w[1]; w2 = w[2];
+                            const float4 w3 = w[3];
+                            left = __float_as_int(w3.x); right = __float_as_int(w3.y);
+                        } else if (next_valid) {
+                            w0 = next0; w1 = next1; w2 = next2; left = next_l; right = next_r;
+                        } else {
+                            // one 128-byte line: the node's boxes, its left child's boxes, the child ids of both
+                            const float4 *w = sc.pair + (size_t)cur_id * 8;
+                            w0 = w[0]; w1 = w[1]; w2 = w[2];
+                            next0 = w[3]; next1 = w[4]; next2 = w[5];
+                            const float4 ids = w[6];
+                            left = __float_as_int(ids.x); right = __float_as_int(ids.y);
+                            next_l = __float_as_int(ids.z); next_r = __float_as_int(ids.w);
+                        }
+                        const bool fetched_pair = PAIR && !next_valid;
+                        const float lmn[3] = {w0.x, w0.y, w0.z}, lmx[3] = {w0.w, w1.x, w1.y};
+                        const float rmn[3] = {w1.z, w1.w, w2.x}, rmx[3] = {w2.y, w2.z, w2.w};
+                        float tl, tr;
+                        const bool hl = slab(lmn, lmx, ray.o, inv, tl) && tl <= current_t;
+                        const bool hr = slab(rmn, rmx, ray.o, inv, tr) && tr <= current_t;
+                        if (COUNT) { cnt.node_visits += 2; cnt.box_tests += 2; }
+                        const bool right_first = NEAR && hl && hr && tr < tl;
+                        if (hl && hr) {
+                            const int later = right_first ? left : right;
+                            const float t_later = right_first ? tl : tr;
+                            if ((int)pending < levels) {
+                                stack[__umul24(pending, (unsigned)nthreads)] = __int_as_float(later);
+                                stack_t[__umul24(pending, (unsigned)nthreads)] = t_later;
+                            } else {
+                                gst[(size_t)((int)pending - levels) * gstride] = make_uint2((unsigned)later, __float_as_uint(t_later));
+                            }
+                            pending++;
+                        }
+                        const bool go_left = hl && !right_first;
+                        const int nxt = go_left ? left : right;
+                        if (!(hl || hr)) cur_k = K_POP;
+                        else if (nxt < 0) { cur_k = 0; cur_s = ~nxt; }
+                        else cur_id = nxt;                  // cur_k stays 1
+                        if (PAIR) next_valid = fetched_pair && go_left && left >= 0;
+                    }
+                } else
                 if (cur_k >= 1) {                       // only traversing lanes have cur_k >= K_POP
                     float4 w0, w1, w2;
                     if (LDSN) {
@@ -685,6 +741,29 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                 }
         };
         auto pop = [&]() {
+                if (GEN) {
+                    if (cur_k == K_POP) {
+                        if (pending == 0) {
+                            cur_k = K_IDLE;
+                        } else {
+                            pending--;
+                            int id;
+                            float t_entry;
+                            if ((int)pending < levels) {
+                                id = __float_as_int(stack[__umul24(pending, (unsigned)nthreads)]);
+                                t_entry = stack_t[__umul24(pending, (unsigned)nthreads)];
+                            } else {
+                                const uint2 e = gst[(size_t)((int)pending - levels) * gstride];
+                                id = (int)e.x; t_entry = __uint_as_float(e.y);
+                            }
+                            if (t_entry <= current_t) {
+                                if (PAIR) next_valid = false;
+                                if (id < 0) { cur_k = 0; cur_s = ~id; }
+                                else { cur_k = 1; cur_id = id; }
+                            }
+                        }
+                    }
+                } else
                 if (cur_k == K_POP) {
                     // one pending child per iteration; an entry whose entry distance no longer passes
                     // the distance test is dropped and the lane tries again next iteration
@@ -1326,6 +1405,31 @@ __global__ __launch_bounds__(256) void k_pair_records(const WideNode *__restrict
     d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
 }
 
+// The same line for a tree with explicit child ids (PT_BUILD_TOPOLOGY_MORTON, n_nodes = n - 1): float4 6 holds the
+// node's child ids and its left child's.
+__global__ __launch_bounds__(256) void k_pair_records_ids(const WideNode *__restrict__ wide, int n_nodes, float4 *__restrict__ pair)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int id = (int)(t >> 1), half = (int)(t & 1);
+    if (id >= n_nodes) return;
+    const float4 own3 = reinterpret_cast<const float4 *>(&wide[id])[3];
+    const int left = __float_as_int(own3.x);
+    float4 *d = pair + (size_t)id * 8;
+    if (!half) {
+        const float4 *s = reinterpret_cast<const float4 *>(&wide[id]);
+        d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+        float4 ids = make_float4(own3.x, own3.y, 0.0f, 0.0f);
+        if (left >= 0) {
+            const float4 c3 = reinterpret_cast<const float4 *>(&wide[left])[3];
+            ids.z = c3.x; ids.w = c3.y;
+        }
+        d[6] = ids;
+    } else if (left >= 0) {
+        const float4 *s = reinterpret_cast<const float4 *>(&wide[left]);
+        d[3] = s[0]; d[4] = s[1]; d[5] = s[2];
+    }
+}
+
 __global__ void k_root_box(const WideNode *__restrict__ wide, float *__restrict__ out6)
 {   // the root's own box = union of its children's boxes (HLSL min/max)
     if (threadIdx.x < 3) {
@@ -1360,6 +1464,9 @@ int ptk_root_box(pt_context *ctx)
 // bit_length(n) + 1 entries can never overflow.
 static size_t stack_bytes(const pt_context *ctx)
 {
+    // a Morton-keyed tree is as high as its codes make it: one entry per internal node on the longest path
+    if (ctx->build_flags & PT_BUILD_TOPOLOGY_MORTON)
+        return (size_t)TRACE_THREADS * sizeof(uint2) * (size_t)(ctx->tree_height <= 16 ? 16 : (ctx->tree_height + 7) / 8 * 8);
     const int levels = 32 - __builtin_clz((unsigned)ctx->n | 1u);
     return (size_t)TRACE_THREADS * sizeof(uint2) * (size_t)(levels + 1 <= 16 ? 16 : 32);
 }
@@ -1429,8 +1536,27 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
         const int cap = (kn.max_threads / 64) * 64;
         if (cap >= 256 && threads > cap) { lds_bytes -= (size_t)levels * 4 * (size_t)(threads - cap); threads = cap; }
     }
+    const bool gen = (ctx->build_flags & PT_BUILD_TOPOLOGY_MORTON) != 0;
+    if (gen) threads = 0;                           // explicit child ids: the records stay in global memory
     const bool lds_nodes = threads >= 256;          // else: node records stay in global memory
-    if (!lds_nodes) {
+    if (gen) {
+        // LDS holds the materials and the first `levels` entries of every lane's (node, distance) stack; a tree higher
+        // than that keeps the rest of the stacks in global memory
+        threads = 1024;
+        if (kn.max_threads >= 256) threads = (kn.max_threads / 64) * 64;
+        const int fit = (int)((160 * 1024 - MAT_SLOTS * 64) / (8 * (size_t)threads));
+        levels = ctx->tree_height < fit ? ctx->tree_height : fit;
+        lds_bytes = MAT_SLOTS * 64 + (size_t)levels * 8 * threads;
+        const size_t deep = (size_t)(ctx->tree_height - levels) * ctx->num_cus * threads;
+        if (ctx->gstack_cap < deep) {
+            PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_gstack) (void)hipFree(ctx->d_gstack);
+            ctx->d_gstack = nullptr;
+            ctx->gstack_cap = 0;
+            PT_HIP(ctx, hipMalloc((void **)&ctx->d_gstack, deep * sizeof(uint2)));
+            ctx->gstack_cap = deep;
+        }
+    } else if (!lds_nodes) {
         // LDS holds the materials and one float per tree level and lane
         levels = 32 - __builtin_clz((unsigned)ctx->n | 1u);
         threads = 1024;
@@ -1453,8 +1579,12 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             ctx->pair_cap = (size_t)ctx->n;
         }
         const long long threads2 = 2ll * ctx->n;
-        hipLaunchKernelGGL(k_pair_records, dim3((unsigned)((threads2 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_wide, ctx->n, levels,
-                           ctx->d_pair);
+        if (gen)
+            hipLaunchKernelGGL(k_pair_records_ids, dim3((unsigned)((threads2 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_wide, ctx->n - 1,
+                               ctx->d_pair);
+        else
+            hipLaunchKernelGGL(k_pair_records, dim3((unsigned)((threads2 + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_wide, ctx->n, levels,
+                               ctx->d_pair);
         PT_HIP(ctx, hipGetLastError());
         ctx->pair_valid = true;
         sv.pair = ctx->d_pair;
@@ -1560,17 +1690,20 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             while (frame_lanes_log2 < 8 && (2u << frame_lanes_log2) <= cnt) frame_lanes_log2++;
             hipLaunchKernelGGL(k_path_seeds, dim3((unsigned)ctx->num_cus * 16u), dim3(256), 0, ctx->stream, ctx->W, (unsigned)npix, cnt,
                                seeds, ctx->d_samples, frame_lanes_log2);
-#define PT_LAUNCH(SLOT, C, L, N) PT_LAUNCH_(SLOT, C, L, N, false)
-#define PT_LAUNCH_G(SLOT, C, N) do { if (use_pair) PT_LAUNCH_(SLOT + 10, C, false, N, true); else PT_LAUNCH_(SLOT, C, false, N, false); } while (0)
-#define PT_LAUNCH_(SLOT, C, L, N, P) do { \
-            if (int rc_ = ensure_lds_limit(ctx, SLOT, &k_trace_persistent<C, L, N, P>, lds_bytes)) return rc_; \
+#define PT_LAUNCH(SLOT, C, L, N) PT_LAUNCH_(SLOT, C, L, N, false, false)
+#define PT_LAUNCH_G(SLOT, C, N) do { \
+            if (gen) { if (use_pair) PT_LAUNCH_(SLOT + 22, C, false, N, true, true); else PT_LAUNCH_(SLOT + 16, C, false, N, false, true); } \
+            else if (use_pair) PT_LAUNCH_(SLOT + 10, C, false, N, true, false); else PT_LAUNCH_(SLOT, C, false, N, false, false); } while (0)
+#define PT_LAUNCH_(SLOT, C, L, N, P, G) do { \
+            if (int rc_ = ensure_lds_limit(ctx, SLOT, &k_trace_persistent<C, L, N, P, G>, lds_bytes)) return rc_; \
             if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream)); \
-            hipLaunchKernelGGL((k_trace_persistent<C, L, N, P>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
-                n_slots, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, seeds, \
+            hipLaunchKernelGGL((k_trace_persistent<C, L, N, P, G>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
+                ctx->d_gstack, n_slots, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, seeds, \
                 ctx->d_samples, ctx->d_counters, ctx->d_work, \
                 order, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, \
                 (uint32_t)chunk, tune); } while (0)
-            // slot of the variant in ctx->lds_attr: COUNT, LDSN, NEAR as bits
+            // slot of the variant in ctx->lds_attr: COUNT, LDSN, NEAR as bits; + 10 with pair lines, + 16 / + 22 for trees with
+            // explicit child ids (without / with pair lines); 8, 9: wavefront; 28, 29: the per-ray kernels
             if (near_first) {
                 if (lds_nodes) { if (ctx->detailed) PT_LAUNCH(7, true, true, true); else PT_LAUNCH(6, false, true, true); }
                 else           { if (ctx->detailed) PT_LAUNCH_G(5, true, true); else PT_LAUNCH_G(4, false, true); }
@@ -1634,6 +1767,7 @@ int ptk_primary(pt_context *ctx, const pt_camera *cam, const uint8_t *d_albedo)
     cb.znear = cam->znear;
     cb.zfar = cam->zfar;
     dim3 grid((ctx->W + 15) / 16, (ctx->H + 15) / 16), block(TRACE_THREADS);
+    if (int rc = ensure_lds_limit(ctx, 28, &k_primary, stack_bytes(ctx))) return rc;
     hipLaunchKernelGGL(k_primary, grid, block, stack_bytes(ctx), ctx->stream, sv, cb, ctx->W, ctx->H,
                        reinterpret_cast<const uchar4 *>(d_albedo), ctx->d_prims,
                        reinterpret_cast<uchar4 *>(ctx->d_diffuse), ctx->d_normal, ctx->d_world);
@@ -1645,6 +1779,7 @@ int ptk_intersect(pt_context *ctx, const float *d_rays8, int n_rays, pt_hit *d_o
 {
     SceneView sv;
     if (int rc = make_view(ctx, sv)) return rc;
+    if (int rc = ensure_lds_limit(ctx, 29, &k_intersect, stack_bytes(ctx))) return rc;
     hipLaunchKernelGGL(k_intersect, dim3((n_rays + TRACE_THREADS - 1) / TRACE_THREADS), dim3(TRACE_THREADS),
                        stack_bytes(ctx), ctx->stream, sv, reinterpret_cast<const float4 *>(d_rays8), n_rays, d_out);
     PT_HIP(ctx, hipGetLastError());

@@ -28,6 +28,7 @@ PT_BUILD_DEFAULT = 0
 PT_BUILD_MORTON_FULL = 1
 PT_BUILD_KARRAS_LINKS = 4
 PT_BUILD_TREE_ONLY = 8
+PT_BUILD_TOPOLOGY_MORTON = 16
 PT_NOALLOC_MAX_PRIMS = 131072
 PT_ACCUM_LITERAL = 0
 PT_ACCUM_LINEAR = 1

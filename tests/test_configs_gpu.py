@@ -25,6 +25,15 @@ def _bits(a):
     return np.ascontiguousarray(a).view(np.uint8)
 
 
+def _same_tree(a, b):
+    """links as integers, boxes with == on floats: min / max of +0 and -0 may keep either zero on the CPU (the
+    loader's x flip makes -0.0 in the reference's scenes)"""
+    for f in ("left", "right", "parent", "index", "padding"):
+        assert np.array_equal(a[f], b[f]), f
+    for f in ("min", "pad", "max"):
+        assert np.array_equal(a["bound"][f], b["bound"][f]), f
+
+
 CAM = dict(eye=(50.0, 50.0, 300.0), at=(50.0, 50.0, 50.0))
 
 
@@ -205,3 +214,91 @@ def test_render_100m_soup_properties(gpu_ctx_factory):
     assert (a[..., :3].max(axis=-1) > 0).mean() > 0.05      # light reaches a part of the image
     ctx.close()
     del d
+
+
+@pytest.mark.parametrize("pair_lines", [True, False])
+@pytest.mark.parametrize("near_first", [False, True])
+@pytest.mark.parametrize("full", [True, False])
+def test_morton_keyed_topology_against_the_oracle(gpu_ctx_factory, monkeypatch, full, near_first, pair_lines):
+    """PT_BUILD_TOPOLOGY_MORTON (NON-PARITY: the radix tree over the sorted codes instead of the reference's tree over
+    the leaf index), n = 200k, with full-resolution codes and with the reference's 15-bit codes (thousands of equal
+    codes, told apart by position).  Tree, G-buffer, linear sums and counters equal the oracle's restatement of
+    the same option bit for bit; the tree is a different one than the reference's, the nearest hits are the same."""
+    n, W, H = 200_000, 200, 150
+    if not pair_lines:
+        monkeypatch.setenv("PTAMD_PAIR_MAX_MIB", "0")
+    prims = make_soup(n, seed=777, dtype=ptamd.PRIM_RENDER)
+    prims["vertices"]["pos"] *= np.float32(100.0)
+    prims["matid"] = np.where(np.arange(n) % 16 == 0, 4, np.arange(n) % 4)
+    flags = ptamd.PT_BUILD_TOPOLOGY_MORTON | (ptamd.PT_BUILD_MORTON_FULL if full else 0)
+    ctx = gpu_ctx_factory()
+    cb, alb = _soup_setup(ctx, prims, W, H, flags, near_first)
+    ob = orc.build_codes_topology(prims.view(orc.PRIM_RENDER), full)
+    assert np.array_equal(ctx.morton(), ob["rays"]["morton_code"])
+    assert np.array_equal(ctx.permutation(), ob["sorted_rays"]["index"])
+    got_tree = ctx.tree()
+    for f in ("left", "right", "parent", "index"):
+        assert np.array_equal(got_tree[f], ob["tree"][f][:2 * n]), f
+    assert got_tree.tobytes() == ob["tree"][:2 * n].tobytes()
+    height = orc.tree_height(ob["tree"], n)
+    print("tree height", height)
+    ocam = orc.default_camera(**CAM); ocam.zfar = 1000.0
+    sc = orc.OracleScene(prims.view(orc.PRIM_RENDER), ob["tree"], cb, stack_size=120, max_segments=8, near_first=near_first)
+    gb = orc.primary(orc.OracleScene(prims.view(orc.PRIM_RENDER), ob["tree"], cb, stack_size=120), ocam, W, H, alb)
+    d, nn, w = ctx.download_gbuffer()
+    assert np.array_equal(d, gb[0]) and np.array_equal(_bits(nn), _bits(gb[1])) and np.array_equal(_bits(w), _bits(gb[2]))
+    ctx.set_detailed_counters(True)
+    seeds = ptamd.frame_seeds(1, 0, 2)
+    ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LINEAR)
+    acc = np.zeros((H, W, 4), np.float32)
+    tot = dict(paths=0, rays=0, node_visits=0, box_tests=0, tri_tests=0)
+    for f in range(2):
+        c = orc.trace_frame_linear(sc, gb, f, seeds[f], acc)
+        tot = {k: tot[k] + c[k] for k in tot}
+    assert np.array_equal(_bits(ctx.linear_sum()), _bits(acc))
+    assert ctx.counters() == tot
+    # against the reference's tree over the same order: fewer node visits
+    ob_ref = orc.build_full_codes(prims.view(orc.PRIM_RENDER)) if full else orc.build(prims.view(orc.PRIM_RENDER))
+    sc_ref = orc.OracleScene(prims.view(orc.PRIM_RENDER), ob_ref["tree"], cb, stack_size=120, max_segments=8, near_first=near_first)
+    acc_ref = np.zeros((H, W, 4), np.float32)
+    c_ref = orc.trace_frame_linear(sc_ref, gb, 0, seeds[0], acc_ref)
+    acc0 = np.zeros((H, W, 4), np.float32)
+    c0 = orc.trace_frame_linear(sc, gb, 0, seeds[0], acc0)
+    print("full", full, "near_first", near_first, "visits/ray", c0["node_visits"] / c0["rays"], "index-keyed", c_ref["node_visits"] / c_ref["rays"])
+    assert c0["node_visits"] < 0.8 * c_ref["node_visits"]
+    assert np.any(acc0 != acc_ref, axis=-1).mean() < 0.01       # other tree, same nearest hits (ties aside)
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_morton_keyed_topology_on_the_reference_scenes(gpu_ctx_factory, golden, scene):
+    """The same option on the reference's scenes (15-bit codes, many ties; node records in global memory)."""
+    W, H = 160, 136
+    g = golden[scene]
+    n = len(g["prims"])
+    ctx = gpu_ctx_factory()
+    ctx.upload_primitives(g["prims"]); ctx.set_constants(g["cb"]); ctx.build(ptamd.PT_BUILD_TOPOLOGY_MORTON); ctx.resize(W, H)
+    ob = orc.build_codes_topology(g["prims"])
+    _same_tree(ctx.tree(), ob["tree"][:2 * n])
+    alb = ptamd.albedo_table(g["mat_table"][:, 0:3], True)
+    ctx.primary_hits(ptamd.default_camera(), alb)
+    gb = ctx.download_gbuffer()
+    sc = orc.OracleScene(g["prims"], ob["tree"], g["cb"], stack_size=120)
+    ogb = orc.primary(sc, orc.default_camera(), W, H, alb)
+    assert all(np.array_equal(_bits(a), _bits(b)) for a, b in zip(gb, ogb))
+    seeds = ptamd.frame_seeds(1, 0, 3)
+    ctx.set_detailed_counters(True)
+    ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LINEAR)
+    acc = np.zeros((H, W, 4), np.float32)
+    tot = dict(paths=0, rays=0, node_visits=0, box_tests=0, tri_tests=0)
+    for f in range(3):
+        c = orc.trace_frame_linear(sc, gb, f, seeds[f], acc)
+        tot = {k: tot[k] + c[k] for k in tot}
+    assert np.array_equal(_bits(ctx.linear_sum()), _bits(acc))
+    assert ctx.counters() == tot
+    # strict-parity stack and the option exclude each other; rebuilding without the flag gives the reference tree again
+    ctx.set_stack_size(15)
+    with pytest.raises(ptamd.PtError):
+        ctx.trace_frames(3, ptamd.frame_seeds(1, 3, 1), ptamd.PT_ACCUM_LINEAR)
+    ctx.set_stack_size(0)
+    ctx.build()
+    _same_tree(ctx.tree(), g["tree"][:2 * n])
