@@ -16,7 +16,9 @@ replicas), and a bounded CPU baseline (the oracle, rank 0, N = 1 only).
 512 spp = 4 steps per GPU (--steps 4).  Same kernels and roofline as scene04; no build or CPU legs are skipped.
 
 --config soup100m: the largest named configuration -- a 100M-triangle random soup (generated on the device) at
-3840x2160, at most 8 rays per path, full-resolution codes, deep stack (NON-PARITY options, see include/ptamd.h).
+3840x2160, at most 8 rays per path, full-resolution codes, tree over the Morton codes (--topology index: the
+reference's index-keyed tree), nearest child first (--near-first 0: the reference's order), deep stack
+(NON-PARITY options, see include/ptamd.h).
 One STEP = one launch of 2 frames.  Node records are read from global memory: this one is bound by HBM.
 
 value = BVH traversals (`intersect()` calls, counted by the kernel) of all ranks / wall time.
@@ -306,6 +308,9 @@ def main():
     ap.add_argument("--soup-tris", type=int, default=100_000_000)
     ap.add_argument("--soup-frames", type=int, default=2)
     ap.add_argument("--near-first", type=int, default=1, help="soup100m: nearest-child-first traversal order (a labelled non-parity option)")
+    ap.add_argument("--topology", default="morton", choices=["morton", "index"],
+                    help="soup100m: tree over the sorted Morton codes (PT_BUILD_TOPOLOGY_MORTON, a labelled non-parity option) "
+                         "or the reference's tree over the leaf index")
     ap.add_argument("--no-build", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -363,8 +368,9 @@ def main():
             cb["mats"][0][k]["ns"] = 1; cb["mats"][0][k]["ni"] = 1; cb["mats"][0][k]["kd"][:3] = kd
         cb["mats"][0][4]["ke"] = 10; cb["mats"][0][4]["ns"] = 1; cb["mats"][0][4]["ni"] = 1; cb["mats"][0][4]["kd"][:3] = (1, 1, 1)
         ctx.set_constants(cb)
-        ctx.build(ptamd.PT_BUILD_MORTON_FULL)
-        ctx.build(ptamd.PT_BUILD_MORTON_FULL)
+        soup_flags = ptamd.PT_BUILD_MORTON_FULL | (ptamd.PT_BUILD_TOPOLOGY_MORTON if args.topology == "morton" else 0)
+        ctx.build(soup_flags)
+        ctx.build(soup_flags)
         scene_build = ctx.build_times()
         ctx.resize(W, H)
         ctx.set_stack_size(32)
@@ -520,6 +526,7 @@ def main():
         if soup_mode:
             workload = (f"synthetic {ctx.n}-triangle soup {W}x{H}, at most 8 rays per path, {total_frames} spp "
                         f"({args.steps} steps x {fpb} frames per GPU), full-resolution codes, deep stack, "
+                        f"{'tree over the Morton codes' if args.topology == 'morton' else 'index-keyed tree'}, "
                         f"{'nearest-child-first' if args.near_first else 'reference'} traversal order (NON-PARITY options)")
             data = "soup generated on the device (torch generator seed 2024), fixed frame seeds mt19937(1), G-buffer by ray cast"
         else:

@@ -1565,7 +1565,8 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
     }
     // pair lines double the node array: past a few GiB the larger footprint (address translation) costs what the
     // saved requests gain, so the largest scenes read the plain 64-byte records
-    const size_t pair_max_nodes = kn.pair_max_mib > 0 ? ((size_t)kn.pair_max_mib << 20) / 128 : 0;
+    // (a tree over the Morton codes keeps a subtree's records close together in memory: the lines pay up to four times that size)
+    const size_t pair_max_nodes = kn.pair_max_mib > 0 ? ((size_t)kn.pair_max_mib << 20) / 128 * (gen ? 4 : 1) : 0;
     const bool use_pair = !lds_nodes && (size_t)ctx->n <= pair_max_nodes;
     if (use_pair && !ctx->pair_valid) {
         // the 128-byte node + left-child lines of the global-memory traversal, made at the first trace after a build
