@@ -60,7 +60,7 @@ static void free_build(pt_context *ctx)
     dev_free(ctx->d_tree);
     dev_free(ctx->d_wide);
     dev_free(ctx->d_pair); ctx->pair_cap = 0; ctx->pair_valid = false;
-    dev_free(ctx->d_leaf_box); ctx->leaf_box_cap = 0;
+    dev_free(ctx->d_links); ctx->links_cap = 0;
     dev_free(ctx->d_gstack); ctx->gstack_cap = 0;
     dev_free(ctx->d_chunk);
     dev_free(ctx->d_shade);
@@ -283,12 +283,12 @@ int pt_build(pt_context *ctx, unsigned flags)
     if ((flags & PT_BUILD_TOPOLOGY_MORTON) && ctx->n < 2) PT_FAIL(ctx, PT_ERR_UNSUPPORTED, "pt_build: PT_BUILD_TOPOLOGY_MORTON needs n >= 2");
     if (int rc = set_device(ctx)) return rc;
     if (int rc = ensure_build_buffers(ctx)) return rc;
-    if ((flags & PT_BUILD_TOPOLOGY_MORTON) && ctx->leaf_box_cap < (size_t)ctx->n) {
+    if ((flags & PT_BUILD_TOPOLOGY_MORTON) && ctx->links_cap < (size_t)ctx->n) {
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        dev_free(ctx->d_leaf_box);
-        ctx->leaf_box_cap = 0;
-        if (int rc = dev_alloc(ctx, &ctx->d_leaf_box, 2 * (size_t)ctx->capacity)) return rc;
-        ctx->leaf_box_cap = (size_t)ctx->capacity;
+        dev_free(ctx->d_links);
+        ctx->links_cap = 0;
+        if (int rc = dev_alloc(ctx, &ctx->d_links, (size_t)ctx->capacity)) return rc;
+        ctx->links_cap = (size_t)ctx->capacity;
     }
     ctx->built = false;
     ctx->tree_exported = false;

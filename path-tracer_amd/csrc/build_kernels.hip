@@ -609,11 +609,13 @@ __global__ __launch_bounds__(256) void k_cost_keys(uint32_t *__restrict__ cost, 
 // position (Karras 2012, section 4).  n keys give n - 1 internal nodes, root 0; children are named
 // by the split position as everywhere else (left = gamma, right = gamma + 1, leaves as ~key).
 //
-// Boxes bottom-up without any inter-workgroup hand-off: a child's common prefix is strictly longer
-// than its parent's, so the nodes are bucketed by prefix length (one stable 8-bit counting pass of the
-// radix sort over the n - 1 lengths) and the buckets are processed longest prefix first, one launch per
-// length.  A node reads its children's records (their two boxes give the child's own box) or the
-// leaf boxes, and writes its record once.
+// Boxes bottom-up without any inter-workgroup hand-off.  A node's descendants have ids inside its key
+// range, so every node whose range lies inside one 1024-key chunk is finished by the workgroup of that
+// chunk through LDS (k_refit_chunk: rounds of "both children done -> my turn", one round per level of
+// the tallest subtree of the chunk), with coalesced reads and writes.  The nodes whose range crosses a
+// chunk border (about one per border and level) are listed by the search kernel with their prefix
+// length; a child's common prefix is strictly longer than its parent's, so they are finished longest
+// prefix first, one small launch per length.
 // ---------------------------------------------------------------------------
 template <typename K>
 __device__ __forceinline__ int lcp_codes(const K *__restrict__ codes, K ci, int i, int j, int n)
@@ -624,87 +626,159 @@ __device__ __forceinline__ int lcp_codes(const K *__restrict__ codes, K ci, int 
     return 8 * (int)sizeof(K) + __clz(i ^ j);          // i != j here
 }
 
+constexpr int LINK_RIGHT_LEAF = 1, LINK_IN_CHUNK = 2;
+// A node that crosses a border has one end of its range (its own id) in its chunk and crosses the border on the other
+// side; the nodes crossing one border are nested, so a chunk holds at most 2 x height of them: 128 slots per chunk
+// cover every tree the build accepts (PT_MAX_TREE_HEIGHT), and a chunk with more sets `overflow` (the build fails).
+constexpr int CROSS_SLOTS = 2 * PT_MAX_TREE_HEIGHT;
+
+// One workgroup per 1024-key chunk.  links[i] = {left child (a leaf as ~key), LINK_* bits}: the right child is the
+// left one's key + 1.  cross[chunk * CROSS_SLOTS + k] = {node, prefix length} for the chunk's border-crossing nodes.
 template <typename K>
-__global__ __launch_bounds__(256) void k_karras_codes(const K *__restrict__ codes, int n, WideNode *__restrict__ wide,
-                                                      uint32_t *__restrict__ prefix_len)
+__global__ __launch_bounds__(PT_REFIT_CHUNK) void k_karras_codes(const K *__restrict__ codes, int n, int2 *__restrict__ links,
+                                                                 uint2 *__restrict__ cross, uint32_t *__restrict__ cross_count,
+                                                                 unsigned *__restrict__ overflow)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n - 1) return;
-    const K ci = codes[i];
-    const int d = (lcp_codes(codes, ci, i, i + 1, n) - lcp_codes(codes, ci, i, i - 1, n) > 0) ? 1 : -1;
-    const int sig_min = lcp_codes(codes, ci, i, i - d, n);
-    int lmax = 2;
-    while (lcp_codes(codes, ci, i, i + lmax * d, n) > sig_min) lmax *= 2;
-    int l = 0;
-    for (int t = lmax / 2; t >= 1; t /= 2)
-        if (lcp_codes(codes, ci, i, i + (l + t) * d, n) > sig_min) l += t;
-    const int j = i + l * d;
-    const int sig_node = lcp_codes(codes, ci, i, j, n);
-    int s = 0, t = l;
-    do {
-        t = (t + 1) >> 1;
-        if (lcp_codes(codes, ci, i, i + (s + t) * d, n) > sig_node) s += t;
-    } while (t > 1);
-    const int gamma = i + s * d + min(d, 0);
-    const int left = (min(i, j) == gamma) ? ~gamma : gamma;
-    const int right = (max(i, j) == gamma + 1) ? ~(gamma + 1) : gamma + 1;
-    reinterpret_cast<float4 *>(&wide[i])[3] = make_float4(__int_as_float(left), __int_as_float(right), 0.0f, 0.0f);
-    prefix_len[i] = (uint32_t)sig_node;
-}
-
-// the leaf half of k_refit_low for the Morton-keyed tree: one key per lane, the box in leaf order
-// (two float4 per key: min.xyz, max.xyz) and, with PACK, the two per-leaf records of the trace kernels
-template <bool PACK>
-__global__ __launch_bounds__(256) void k_leaf_records(const uint32_t *__restrict__ perm, const BoxRec *__restrict__ boxes,
-                                                      const uint4 *__restrict__ prims16, int n, float4 *__restrict__ leaf_box,
-                                                      TriIsect *__restrict__ tri, TriShade *__restrict__ shade)
-{
-    const int key = blockIdx.x * 256 + threadIdx.x;
-    if (key >= n) return;
-    const int p = (int)perm[key];
-    float b[6];
-    if (PACK) {
-        const float4 *src = reinterpret_cast<const float4 *>(prims16 + (size_t)p * (PRIM_DW / 4));
-        const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
-        const float A[3] = {v0.x, v0.y, v0.z}, B[3] = {v1.z, v1.w, v2.x}, C[3] = {v3.x, v3.y, v3.z};
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            // math3d.h:13-23, as in k_bounds
-            const float x = A[k], y = B[k], z = C[k];
-            const float yz_max = (y > z) ? y : z, yz_min = (y < z) ? y : z;
-            b[3 + k] = (x > yz_max) ? x : yz_max;
-            b[k] = (x < yz_min) ? x : yz_min;
+    __shared__ unsigned cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const int i = blockIdx.x * PT_REFIT_CHUNK + threadIdx.x;
+    if (i < n - 1) {
+        const K ci = codes[i];
+        const int d = (lcp_codes(codes, ci, i, i + 1, n) - lcp_codes(codes, ci, i, i - 1, n) > 0) ? 1 : -1;
+        const int sig_min = lcp_codes(codes, ci, i, i - d, n);
+        int lmax = 2;
+        while (lcp_codes(codes, ci, i, i + lmax * d, n) > sig_min) lmax *= 2;
+        int l = 0;
+        for (int t = lmax / 2; t >= 1; t /= 2)
+            if (lcp_codes(codes, ci, i, i + (l + t) * d, n) > sig_min) l += t;
+        const int j = i + l * d;
+        const int sig_node = lcp_codes(codes, ci, i, j, n);
+        int s = 0, t = l;
+        do {
+            t = (t + 1) >> 1;
+            if (lcp_codes(codes, ci, i, i + (s + t) * d, n) > sig_node) s += t;
+        } while (t > 1);
+        const int gamma = i + s * d + min(d, 0);
+        const int lo = min(i, j), hi = max(i, j);
+        const bool crossing = (lo >> PT_REFIT_CHUNK_LOG2) != (hi >> PT_REFIT_CHUNK_LOG2);
+        links[i] = make_int2(lo == gamma ? ~gamma : gamma, (hi == gamma + 1 ? LINK_RIGHT_LEAF : 0) | (crossing ? 0 : LINK_IN_CHUNK));
+        if (crossing) {
+            const unsigned slot = atomicAdd(&cnt, 1u);
+            if (slot < (unsigned)CROSS_SLOTS) cross[(size_t)blockIdx.x * CROSS_SLOTS + slot] = make_uint2((unsigned)i, (unsigned)sig_node);
         }
-        float4 *td = reinterpret_cast<float4 *>(&tri[key]);
-        td[0] = make_float4(A[0], A[1], A[2], __int_as_float(p));
-        td[1] = make_float4(B[0] - A[0], B[1] - A[1], B[2] - A[2], 0.0f);
-        td[2] = make_float4(C[0] - A[0], C[1] - A[1], C[2] - A[2], 0.0f);
-        float4 *sd = reinterpret_cast<float4 *>(&shade[key]);
-        sd[0] = make_float4(v0.w, v1.x, v1.y, v4.z);
-        sd[1] = make_float4(v2.y, v2.z, v2.w, 0.0f);
-        sd[2] = make_float4(v3.w, v4.x, v4.y, 0.0f);
-    } else {
-        const float4 *src = reinterpret_cast<const float4 *>(&boxes[p]);
-        const float4 lo = src[0], hi = src[1];
-        b[0] = lo.x; b[1] = lo.y; b[2] = lo.z; b[3] = hi.x; b[4] = hi.y; b[5] = hi.z;
     }
-    leaf_box[2 * (size_t)key] = make_float4(b[0], b[1], b[2], 0.0f);
-    leaf_box[2 * (size_t)key + 1] = make_float4(b[3], b[4], b[5], 0.0f);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cross_count[blockIdx.x] = min(cnt, (unsigned)CROSS_SLOTS);
+        if (cnt > (unsigned)CROSS_SLOTS) atomicOr(overflow, 1u);
+    }
 }
 
-// exclusive prefix of the 256 bucket sizes (one workgroup)
-__global__ __launch_bounds__(256) void k_level_offsets(const uint32_t *__restrict__ digit_total, uint32_t *__restrict__ level_off)
+__device__ __forceinline__ void write_wide_h(WideNode *__restrict__ w, const float *L, const float *R, int left, int right, int height)
 {
-    __shared__ uint32_t sh[5];
-    uint32_t total;
-    const uint32_t ex = block_excl_scan_256(digit_total[threadIdx.x], sh, &total);
-    level_off[threadIdx.x] = ex;
-    if (threadIdx.x == 255) level_off[256] = total;
+    float4 *dst = reinterpret_cast<float4 *>(w);
+    dst[0] = make_float4(L[0], L[1], L[2], L[3]);
+    dst[1] = make_float4(L[4], L[5], R[0], R[1]);
+    dst[2] = make_float4(R[2], R[3], R[4], R[5]);
+    dst[3] = make_float4(__int_as_float(left), __int_as_float(right), __int_as_float(height), 0.0f);   // height: levels below the node
 }
 
-// box and height of child `c` of a node of the Morton-keyed tree
-__device__ __forceinline__ void gen_child_box(int c, const WideNode *__restrict__ wide, const float4 *__restrict__ leaf_box,
-                                              float *B, int &height)
+// A node the rounds below cannot finish (a chunk subtree higher than the supported tree height) gets this height,
+// which every ancestor inherits: the build then fails on the root's height.
+constexpr int HEIGHT_UNFINISHED = 1 << 20;
+
+// One workgroup per 1024 keys: the leaves' boxes (and, with PACK, the two per-leaf records of the trace
+// kernels, as k_refit_low), then every node whose key range lies inside the chunk.
+template <bool PACK>
+__global__ __launch_bounds__(PT_REFIT_CHUNK) void k_refit_chunk(const uint32_t *__restrict__ perm, const BoxRec *__restrict__ boxes,
+                                                     const uint4 *__restrict__ prims16, int n, const int2 *__restrict__ links,
+                                                     WideNode *__restrict__ wide, TriIsect *__restrict__ tri, TriShade *__restrict__ shade)
+{
+    __shared__ float lb[6][PT_REFIT_CHUNK];          // leaf boxes
+    __shared__ float nb[6][PT_REFIT_CHUNK];          // node boxes
+    __shared__ int hh[PT_REFIT_CHUNK];               // node heights; 0 = not finished yet
+    const int t = threadIdx.x;
+    const int base = blockIdx.x * PT_REFIT_CHUNK;
+    const int key = base + t;
+    if (key < n) {
+        const int p = (int)perm[key];
+        float b[6];
+        if (PACK) {
+            const float4 *src = reinterpret_cast<const float4 *>(prims16 + (size_t)p * (PRIM_DW / 4));
+            const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
+            const float A[3] = {v0.x, v0.y, v0.z}, B[3] = {v1.z, v1.w, v2.x}, C[3] = {v3.x, v3.y, v3.z};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                // math3d.h:13-23, as in k_bounds
+                const float x = A[k], y = B[k], z = C[k];
+                const float yz_max = (y > z) ? y : z, yz_min = (y < z) ? y : z;
+                b[3 + k] = (x > yz_max) ? x : yz_max;
+                b[k] = (x < yz_min) ? x : yz_min;
+            }
+            float4 *td = reinterpret_cast<float4 *>(&tri[key]);
+            td[0] = make_float4(A[0], A[1], A[2], __int_as_float(p));
+            td[1] = make_float4(B[0] - A[0], B[1] - A[1], B[2] - A[2], 0.0f);
+            td[2] = make_float4(C[0] - A[0], C[1] - A[1], C[2] - A[2], 0.0f);
+            float4 *sd = reinterpret_cast<float4 *>(&shade[key]);
+            sd[0] = make_float4(v0.w, v1.x, v1.y, v4.z);
+            sd[1] = make_float4(v2.y, v2.z, v2.w, 0.0f);
+            sd[2] = make_float4(v3.w, v4.x, v4.y, 0.0f);
+        } else {
+            const float4 *src = reinterpret_cast<const float4 *>(&boxes[p]);
+            const float4 lo = src[0], hi = src[1];
+            b[0] = lo.x; b[1] = lo.y; b[2] = lo.z; b[3] = hi.x; b[4] = hi.y; b[5] = hi.z;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) lb[c][t] = b[c];
+    }
+    int left = 0, right = 0;
+    bool todo = false;
+    if (key < n - 1) {
+        const int2 ln = links[key];
+        left = ln.x;
+        const int gamma = left < 0 ? ~left : left;
+        right = (ln.y & LINK_RIGHT_LEAF) ? ~(gamma + 1) : gamma + 1;
+        todo = (ln.y & LINK_IN_CHUNK) != 0;
+    }
+    hh[t] = 0;
+    __syncthreads();
+    // every descendant of a node of this chunk is a leaf or a node of this chunk: slots left - base, ~left - base
+    for (int round = 0; round <= PT_MAX_TREE_HEIGHT; round++) {
+        bool ready = false;
+        float L[6], R[6];
+        int h = 0;
+        if (todo) {
+            const int hl = left < 0 ? 0 : hh[left - base], hr = right < 0 ? 0 : hh[right - base];
+            ready = (left < 0 || hl > 0) && (right < 0 || hr > 0);
+            if (ready) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    L[c] = left < 0 ? lb[c][~left - base] : nb[c][left - base];
+                    R[c] = right < 0 ? lb[c][~right - base] : nb[c][right - base];
+                }
+                h = 1 + max(hl, hr);
+            }
+        }
+        if (!__syncthreads_or(todo)) break;          // also: every read of this round precedes its writes
+        if (ready) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) { nb[c][t] = fminf(L[c], R[c]); nb[3 + c][t] = fmaxf(L[3 + c], R[3 + c]); }
+            hh[t] = h;
+            write_wide_h(&wide[key], L, R, left, right, h);
+            todo = false;
+        }
+        __syncthreads();
+    }
+    if (todo) {
+        const float z[6] = {0, 0, 0, 0, 0, 0};
+        write_wide_h(&wide[key], z, z, left, right, HEIGHT_UNFINISHED);
+    }
+}
+
+// box and height of child `c` of a node whose range crosses a chunk border
+__device__ __forceinline__ void cross_child_box(int c, const WideNode *__restrict__ wide, const uint32_t *__restrict__ perm,
+                                                const BoxRec *__restrict__ boxes, float *B, int &height)
 {
     if (c >= 0) {
         const float4 *w = reinterpret_cast<const float4 *>(&wide[c]);
@@ -713,31 +787,35 @@ __device__ __forceinline__ void gen_child_box(int c, const WideNode *__restrict_
         B[3] = fmaxf(w0.w, w2.y); B[4] = fmaxf(w1.x, w2.z); B[5] = fmaxf(w1.y, w2.w);
         height = __float_as_int(w3.z);
     } else {
-        const float4 lo = leaf_box[2 * (size_t)~c], hi = leaf_box[2 * (size_t)~c + 1];
+        const float4 *src = reinterpret_cast<const float4 *>(&boxes[perm[~c]]);
+        const float4 lo = src[0], hi = src[1];
         B[0] = lo.x; B[1] = lo.y; B[2] = lo.z; B[3] = hi.x; B[4] = hi.y; B[5] = hi.z;
         height = 0;
     }
 }
 
-// the nodes whose prefix length is `level`: nodes[level_off[level] .. level_off[level + 1])
-__global__ __launch_bounds__(256) void k_refit_level(int level, const uint32_t *__restrict__ level_off,
-                                                     const uint32_t *__restrict__ nodes, WideNode *__restrict__ wide,
-                                                     const float4 *__restrict__ leaf_box)
+// the listed nodes whose prefix length is `level`: one lane per chunk walks the chunk's few entries
+__global__ __launch_bounds__(256) void k_refit_cross(int level, int nchunks, const uint2 *__restrict__ cross,
+                                                     const uint32_t *__restrict__ cross_count,
+                                                     const int2 *__restrict__ links, WideNode *__restrict__ wide,
+                                                     const uint32_t *__restrict__ perm, const BoxRec *__restrict__ boxes)
 {
-    const uint32_t begin = level_off[level], end = level_off[level + 1];
-    for (uint32_t idx = begin + blockIdx.x * 256u + threadIdx.x; idx < end; idx += gridDim.x * 256u) {
-        const int node = (int)nodes[idx];
-        const float4 ids = reinterpret_cast<const float4 *>(&wide[node])[3];
-        const int left = __float_as_int(ids.x), right = __float_as_int(ids.y);
-        float L[6], R[6];
-        int hl, hr;
-        gen_child_box(left, wide, leaf_box, L, hl);
-        gen_child_box(right, wide, leaf_box, R, hr);
-        float4 *dst = reinterpret_cast<float4 *>(&wide[node]);
-        dst[0] = make_float4(L[0], L[1], L[2], L[3]);
-        dst[1] = make_float4(L[4], L[5], R[0], R[1]);
-        dst[2] = make_float4(R[2], R[3], R[4], R[5]);
-        dst[3] = make_float4(ids.x, ids.y, __int_as_float(1 + max(hl, hr)), 0.0f);     // height: levels below the node
+    for (int chunk = blockIdx.x * 256 + threadIdx.x; chunk < nchunks; chunk += gridDim.x * 256) {
+        const unsigned count = cross_count[chunk];
+        for (unsigned k = 0; k < count; k++) {
+            const uint2 e = cross[(size_t)chunk * CROSS_SLOTS + k];
+            if ((int)e.y != level) continue;
+            const int node = (int)e.x;
+            const int2 ln = links[node];
+            const int left = ln.x, gamma = left < 0 ? ~left : left;
+            const int right = (ln.y & LINK_RIGHT_LEAF) ? ~(gamma + 1) : gamma + 1;
+            float L[6], R[6];
+            int hl, hr;
+            cross_child_box(left, wide, perm, boxes, L, hl);
+            cross_child_box(right, wide, perm, boxes, R, hr);
+            const int h = 1 + max(hl, hr);
+            write_wide_h(&wide[node], L, R, left, right, h > HEIGHT_UNFINISHED ? HEIGHT_UNFINISHED : h);
+        }
     }
 }
 
@@ -874,29 +952,30 @@ static int run_build(pt_context *ctx, const BuildBufs &b, const uint4 *prims16, 
         // counting pass of the sort over the n - 1 lengths), boxes bucket by bucket from the longest prefix up
         const int sb = *sorted_buf, other = sb ^ 1;
         const uint32_t *perm = b.vals[sb];
-        uint32_t *prefix_len = static_cast<uint32_t *>(b.keys[other]);   // the ping-pong half the sort left free
-        uint32_t *nodes = b.vals[other];
-        uint32_t *level_off = b.digit_total + 8 * 256;
-        const int grid_i = (n - 1 + 255) / 256;
-        if (full) hipLaunchKernelGGL(k_karras_codes<uint64_t>, dim3(grid_i), dim3(256), 0, st, static_cast<const uint64_t *>(b.keys[sb]), n,
-                                     b.wide, prefix_len);
-        else      hipLaunchKernelGGL(k_karras_codes<uint32_t>, dim3(grid_i), dim3(256), 0, st, static_cast<const uint32_t *>(b.keys[sb]), n,
-                                     b.wide, prefix_len);
-        {
-            uint32_t *const kb[2] = {nullptr, nullptr};
-            uint32_t *const vb[2] = {nodes, nullptr};
-            (void)radix_sort_passes<uint32_t>(st, prefix_len, n - 1, 1, kb, vb, b.block_hist, b.digit_total);
-            hipLaunchKernelGGL(k_level_offsets, dim3(1), dim3(256), 0, st, b.digit_total, level_off);
-        }
+        // the halves of the sort's ping-pong buffers that it left free: n x 8 bytes and n x 4 bytes
+        uint2 *cross = static_cast<uint2 *>(b.keys[other]);              // CROSS_SLOTS x 8 bytes per 1024 keys
+        uint32_t *cross_count = b.vals[other];
+        unsigned *overflow = b.digit_total + 8 * 256;
+        const int nchunks = (n + PT_REFIT_CHUNK - 1) / PT_REFIT_CHUNK;
+        PT_HIP(ctx, hipMemsetAsync(overflow, 0, sizeof(unsigned), st));
+        if (full) hipLaunchKernelGGL(k_karras_codes<uint64_t>, dim3(nchunks), dim3(PT_REFIT_CHUNK), 0, st, static_cast<const uint64_t *>(b.keys[sb]), n,
+                                     b.links, cross, cross_count, overflow);
+        else      hipLaunchKernelGGL(k_karras_codes<uint32_t>, dim3(nchunks), dim3(PT_REFIT_CHUNK), 0, st, static_cast<const uint32_t *>(b.keys[sb]), n,
+                                     b.links, cross, cross_count, overflow);
         if (ev) PT_HIP(ctx, hipEventRecord(ev[PT_STAGE_TOPOLOGY + 1], st));
         if (flags & PT_BUILD_TREE_ONLY)
-            hipLaunchKernelGGL(k_leaf_records<false>, dim3(grid_n), dim3(256), 0, st, perm, b.boxes, prims16, n, b.leaf_box, b.tri, b.shade);
+            hipLaunchKernelGGL(k_refit_chunk<false>, dim3(nchunks), dim3(PT_REFIT_CHUNK), 0, st, perm, b.boxes, prims16, n, b.links, b.wide, b.tri, b.shade);
         else
-            hipLaunchKernelGGL(k_leaf_records<true>, dim3(grid_n), dim3(256), 0, st, perm, b.boxes, prims16, n, b.leaf_box, b.tri, b.shade);
-        const int longest = (full ? 64 : 32) + 31;           // code bits + the position bits that separate equal codes
-        const unsigned level_grid = (unsigned)std::min(grid_i, 8 * ctx->num_cus);
-        for (int level = longest; level >= 0; level--)
-            hipLaunchKernelGGL(k_refit_level, dim3(level_grid), dim3(256), 0, st, level, level_off, nodes, b.wide, b.leaf_box);
+            hipLaunchKernelGGL(k_refit_chunk<true>, dim3(nchunks), dim3(PT_REFIT_CHUNK), 0, st, perm, b.boxes, prims16, n, b.links, b.wide, b.tri, b.shade);
+        if (nchunks > 1) {
+            // prefix lengths a border-crossing node can have: the codes' leading zero bits are common to all keys, and two
+            // positions on either side of a border differ in bit 10 or above (equal codes: key bits + clz(i ^ j))
+            const int longest = (full ? 64 : 32) + 31 - PT_REFIT_CHUNK_LOG2;
+            const int shortest = full ? 1 : 17;
+            const unsigned level_grid = (unsigned)std::min((nchunks + 255) / 256, 4 * ctx->num_cus);
+            for (int level = longest; level >= shortest; level--)
+                hipLaunchKernelGGL(k_refit_cross, dim3(level_grid), dim3(256), 0, st, level, nchunks, cross, cross_count, b.links, b.wide, perm, b.boxes);
+        }
         if (ev) PT_HIP(ctx, hipEventRecord(ev[PT_STAGE_REFIT + 1], st));
         PT_HIP(ctx, hipGetLastError());
         return PT_OK;
@@ -942,7 +1021,7 @@ int ptk_build(pt_context *ctx, unsigned flags)
     b.vals[0] = ctx->d_vals[0]; b.vals[1] = ctx->d_vals[1];
     b.morton = ctx->d_morton; b.block_hist = ctx->d_block_hist; b.digit_total = ctx->d_digit_total;
     b.wide = ctx->d_wide; b.chunk = ctx->d_chunk; b.shade = ctx->d_shade; b.tri = ctx->d_tri_sorted;
-    b.leaf_box = ctx->d_leaf_box;
+    b.links = ctx->d_links;
     const bool full = (flags & PT_BUILD_MORTON_FULL) != 0;
     if (int rc = run_build(ctx, b, reinterpret_cast<const uint4 *>(ctx->d_prims), ctx->n, flags, ctx->ev, &ctx->sorted_buf)) return rc;
     ctx->morton_bits = full ? 64 : 32;
@@ -951,11 +1030,14 @@ int ptk_build(pt_context *ctx, unsigned flags)
     if (flags & PT_BUILD_TOPOLOGY_MORTON) {
         // the traversal stacks are sized by the height of the tree, which only the finished tree tells
         int h = 0;
+        unsigned overflow = 0;
         PT_HIP(ctx, hipMemcpyAsync(&h, &ctx->d_wide[0].pad[0], sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        PT_HIP(ctx, hipMemcpyAsync(&overflow, ctx->d_digit_total + 8 * 256, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (overflow) h = PT_MAX_TREE_HEIGHT + 1;           // more border-crossing nodes in a chunk than any accepted tree has
         if (h < 1 || h > PT_MAX_TREE_HEIGHT)
-            PT_FAIL(ctx, PT_ERR_UNSUPPORTED, "pt_build: PT_BUILD_TOPOLOGY_MORTON gave a tree of height " + std::to_string(h) +
-                    " (limit " + std::to_string(PT_MAX_TREE_HEIGHT) + "); build without the flag");
+            PT_FAIL(ctx, PT_ERR_UNSUPPORTED, "pt_build: PT_BUILD_TOPOLOGY_MORTON gave a tree higher than the traversal stacks are sized for (height " +
+                    std::to_string(h) + ", limit " + std::to_string(PT_MAX_TREE_HEIGHT) + "); build without the flag");
         ctx->tree_height = h;
     }
     // the per-leaf records of the trace kernels were written by the refit (unless PT_BUILD_TREE_ONLY); what

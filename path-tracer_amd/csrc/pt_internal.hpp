@@ -81,8 +81,8 @@ struct BuildBufs {
     uint32_t *vals[2] = {nullptr, nullptr};
     void *morton = nullptr;             // n codes in primitive order, 4 or 8 bytes each
     uint32_t *block_hist = nullptr;     // 256 per PT_SORT_TILE keys
-    uint32_t *digit_total = nullptr;    // 8 * 256, followed by 512 words for the bucket offsets of PT_BUILD_TOPOLOGY_MORTON
-    float4 *leaf_box = nullptr;         // PT_BUILD_TOPOLOGY_MORTON only: 2 per key (min.xyz, max.xyz in leaf order)
+    uint32_t *digit_total = nullptr;    // 8 * 256, followed by 512 spare words (PT_BUILD_TOPOLOGY_MORTON: a counter)
+    int2 *links = nullptr;              // PT_BUILD_TOPOLOGY_MORTON only: n {left child, flags}
     WideNode *wide = nullptr;           // n
     ChunkBox *chunk = nullptr;          // per 1024 keys, plus the upper levels' groups
     TriShade *shade = nullptr;          // n + 1 (unused with PT_BUILD_TREE_ONLY)
@@ -130,8 +130,8 @@ struct pt_context {
     int sorted_buf = 0;               // which of d_keys/d_vals holds the sorted result
     uint32_t *d_block_hist = nullptr; // 256 * nblocks
     uint32_t *d_digit_total = nullptr;// 8 * 256 + 512
-    float4 *d_leaf_box = nullptr;     // 2 per key, allocated by the first PT_BUILD_TOPOLOGY_MORTON build
-    size_t leaf_box_cap = 0;
+    int2 *d_links = nullptr;          // n, allocated by the first PT_BUILD_TOPOLOGY_MORTON build
+    size_t links_cap = 0;
     int tree_height = 0;              // PT_BUILD_TOPOLOGY_MORTON: internal nodes on the longest root-to-leaf path
     uint2 *d_gstack = nullptr;        // traversal-stack entries beyond the LDS part (Morton-keyed trees deeper than that)
     size_t gstack_cap = 0;            // entries

@@ -1,8 +1,9 @@
 """Small torch-free target for rocprofv3 counter passes:
   trace            scene04 1162x1008, 3 launches of 128 frames (the benchmark's step)
   build [n]        n-triangle soup (default 10M), 3 tree-only builds and 3 default builds
-  soup [n] [near]  n-triangle soup (default 10M) rendered with the options of the largest configuration (full-resolution
-                   codes, deep stack, at most 8 rays per path, node records in global memory), 1920x1080, 2 launches of 2 frames"""
+  soup [n] [near] [morton]  n-triangle soup (default 10M) rendered with the options of the largest configuration
+                   (full-resolution codes, deep stack, at most 8 rays per path, node records in global memory; near: nearest
+                   child first; morton: PT_BUILD_TOPOLOGY_MORTON), 1920x1080, 2 launches of 2 frames"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,7 +23,8 @@ if mode == "trace":
     print(ctx.counters())
 elif mode == "soup":
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
-    near = len(sys.argv) > 3 and sys.argv[3] == "near"
+    near = "near" in sys.argv[3:]
+    topo = ptamd.PT_BUILD_TOPOLOGY_MORTON if "morton" in sys.argv[3:] else 0
     prims = soup(n)
     prims["vertices"]["pos"] *= np.float32(100.0)
     prims["matid"] = np.where(np.arange(n) % 16 == 0, 4, np.arange(n) % 4)
@@ -31,7 +33,7 @@ elif mode == "soup":
     for k in range(4):
         cb["mats"][0][k]["ns"] = 1; cb["mats"][0][k]["ni"] = 1; cb["mats"][0][k]["kd"][:3] = (0.7, 0.6, 0.5)
     cb["mats"][0][4]["ke"] = 10; cb["mats"][0][4]["ns"] = 1; cb["mats"][0][4]["ni"] = 1; cb["mats"][0][4]["kd"][:3] = (1, 1, 1)
-    ctx.upload_primitives(prims); ctx.set_constants(cb); ctx.build(ptamd.PT_BUILD_MORTON_FULL)
+    ctx.upload_primitives(prims); ctx.set_constants(cb); ctx.build(ptamd.PT_BUILD_MORTON_FULL | topo)
     ctx.set_stack_size(32); ctx.set_max_segments(8)
     ctx.set_traversal_order(ptamd.PT_TRAVERSAL_NEAR_FIRST if near else ptamd.PT_TRAVERSAL_REFERENCE)
     ctx.resize(1920, 1080)

@@ -4,6 +4,13 @@ import sys
 import numpy as np
 import pytest
 
+try:
+    # PyTorch-ROCm brings its own HIP runtime under the soname libptamd.so links against; whichever is loaded first
+    # serves the whole process, and torch does not find the GPU through the other one: load torch's first
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))

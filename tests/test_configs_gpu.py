@@ -212,8 +212,89 @@ def test_render_100m_soup_properties(gpu_ctx_factory):
     assert np.all(a[..., 3] == frames) and np.isfinite(a).all() and np.all(a[..., :3] >= 0)
     assert c["paths"] == W * H * frames and 0.5 * c["paths"] < c["rays"] <= 8 * c["paths"]
     assert (a[..., :3].max(axis=-1) > 0).mean() > 0.05      # light reaches a part of the image
+    # the same scene through the tree over the Morton codes (another non-parity option): a different tree finds the
+    # same nearest hits, so the image is the same except where two triangles are hit at equal distance
+    ctx.build(ptamd.PT_BUILD_MORTON_FULL | ptamd.PT_BUILD_TOPOLOGY_MORTON)
+    print("100M build ms, tree over the codes", ctx.build_times())
+    ctx.set_detailed_counters(True)
+    ctx.reset_accumulation(); ctx.reset_counters()
+    ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LINEAR)
+    a2, c2 = ctx.linear_sum(), ctx.counters()
+    assert np.all(a2[..., 3] == frames) and c2["paths"] == c["paths"]
+    differing = np.any(a2 != a, axis=-1).mean()
+    print("pixels that differ between the two trees", differing, "visits per ray", c2["node_visits"] / c2["rays"])
+    assert differing < 0.01 and abs(c2["rays"] - c["rays"]) < 0.001 * c["rays"]
     ctx.close()
     del d
+
+
+def test_build_20m_morton_keyed_tree_properties(gpu_ctx_factory):
+    """PT_BUILD_TOPOLOGY_MORTON at 20M triangles (about 20k chunks of keys and their border-crossing nodes), checked
+    on the device over ALL nodes: n - 1 internal nodes, every node but the root is the child of exactly one node,
+    parents consistent, every internal box the union of its children's, leaves follow the sorted order, and the
+    radix-tree property: the keys below a node share a longer code prefix with each other than with the keys next
+    to the node's range."""
+    import torch
+    n = 20_000_000
+    ctx = gpu_ctx_factory()
+    d = device_soup(n, seed=99)
+    ctx.upload_primitives_device(d.data_ptr(), n)
+    ctx.build(ptamd.PT_BUILD_MORTON_FULL | ptamd.PT_BUILD_TOPOLOGY_MORTON)
+    print("20M build ms", ctx.build_times())
+    perm = torch.from_numpy(ctx.permutation()).to("cuda").long()
+    codes = torch.from_numpy(ctx.morton().view(np.int64)).to("cuda")[perm]          # sorted, below 2^63
+    t = torch.from_numpy(ctx.tree().view(np.int32).reshape(2 * n, 12)).to("cuda")
+    left, right, parent, index = t[:n - 1, 0].long(), t[:n - 1, 1].long(), t[:, 2].long(), t[:, 3]
+    fb = t.view(torch.float32)
+    bmin, bmax = fb[:, 4:7], fb[:, 8:11]
+    ar = torch.arange(n - 1, device="cuda")
+    assert bool(torch.all(parent[left] == ar)) and bool(torch.all(parent[right] == ar))
+    assert bool(torch.all(bmin[:n - 1] == torch.minimum(bmin[left], bmin[right])))
+    assert bool(torch.all(bmax[:n - 1] == torch.maximum(bmax[left], bmax[right])))
+    kids = torch.cat([left, right])
+    assert int(torch.unique(kids).numel()) == 2 * n - 2 and int(kids.min()) == 1      # all nodes but the root, once each
+    assert bool(torch.all(t[n - 1] == 0))                                            # the unused slot
+    assert bool(torch.all(index[n:].long() == perm))
+    pos = d.view(n, 20)[:, [0, 1, 2, 6, 7, 8, 12, 13, 14]].reshape(n, 3, 3)
+    assert bool(torch.all(bmin[n:] == pos.min(dim=1).values[perm])) and bool(torch.all(bmax[n:] == pos.max(dim=1).values[perm]))
+    # children are named by the split position: left = gamma (or leaf n + gamma), right = gamma + 1 (or leaf n + gamma + 1)
+    gamma = torch.where(left >= n, left - n, left)
+    assert bool(torch.all(torch.where(right >= n, right - n, right) == gamma + 1))
+    # key range of every node from its leftmost / rightmost descendants, top-down over the (at most 64) levels
+    lo = torch.full((2 * n,), -1, dtype=torch.int64, device="cuda"); hi = lo.clone()
+    lo[0], hi[0] = 0, n - 1
+    frontier = torch.zeros(1, dtype=torch.int64, device="cuda")
+    levels = 0
+    while frontier.numel():
+        l, r = left[frontier], right[frontier]
+        g = gamma[frontier]
+        lo[l], hi[l] = lo[frontier], g
+        lo[r], hi[r] = g + 1, hi[frontier]
+        nxt = torch.cat([l, r])
+        frontier = nxt[nxt < n - 1]
+        levels += 1
+    assert levels <= 64
+    assert bool(torch.all(lo[n:] == torch.arange(n, device="cuda"))) and bool(torch.all(hi[n:] == lo[n:]))
+    a, b = lo[:n - 1], hi[:n - 1]
+
+    def msb(x):                  # index of the highest set bit of positive int64 values
+        r = torch.zeros_like(x)
+        for sh in (32, 16, 8, 4, 2, 1):
+            m = (x >> sh) != 0
+            r += torch.where(m, sh, 0)
+            x = torch.where(m, x >> sh, x)
+        return r
+
+    def prefix(i, j):            # common prefix of the (code, position) keys i != j; codes are below 2^63
+        x = codes[i] ^ codes[j]
+        return torch.where(x != 0, 63 - msb(x.clamp(min=1)), 64 + 31 - msb((i ^ j).clamp(min=1)))
+    inner = prefix(a, b)
+    before = torch.where(a > 0, prefix(a, (a - 1).clamp(min=0)), torch.full_like(a, -1))
+    after = torch.where(b < n - 1, prefix(b, (b + 1).clamp(max=n - 1)), torch.full_like(a, -1))
+    assert bool(torch.all(inner > before)) and bool(torch.all(inner > after))
+    # and the split is where the prefix of the range ends: the two keys around gamma differ in the first bit after it
+    assert bool(torch.all(prefix(gamma, gamma + 1) == inner))
+    ctx.close()
 
 
 @pytest.mark.parametrize("pair_lines", [True, False])
