@@ -383,3 +383,84 @@ def test_morton_keyed_topology_on_the_reference_scenes(gpu_ctx_factory, golden, 
     ctx.set_stack_size(0)
     ctx.build()
     _same_tree(ctx.tree(), g["tree"][:2 * n])
+
+
+def _single_bit_scene(bits, duplicates):
+    """Triangles whose full-resolution codes are 0 (`duplicates` times) and single bits: their radix tree is a
+    comb, one level per distinct code, plus the levels that tell the equal codes apart by position."""
+    cells = 2097151.0
+    cent = [(0.5, 0.5, 0.5)] * duplicates
+    for b in range(bits):
+        axis, j = 2 - (b % 3), b // 3             # bit b of the code: axis x is the highest of each triple
+        c = [0.5, 0.5, 0.5]
+        c[axis] = float(2 ** j) + 0.5
+        cent.append(tuple(c))
+    n = len(cent) + 1
+    prims = np.zeros(n, dtype=ptamd.PRIM_RENDER)
+    c = np.array(cent, dtype=np.float32)
+    prims["vertices"]["pos"][:-1, 0] = c - np.float32(0.25)
+    prims["vertices"]["pos"][:-1, 1] = c
+    prims["vertices"]["pos"][:-1, 2] = c + np.float32(0.25)
+    prims["vertices"]["pos"][-1, 1] = cells + 0.25        # spans the scene box: [-0.25, cells + 0.25] would shift the grid,
+    prims["vertices"]["pos"][-1, 0] = -0.25               # so the box is made symmetric around the cell grid instead
+    prims["vertices"]["pos"][-1, 2] = -0.25
+    prims["vertices"]["normal"][:, :, 1] = 1.0
+    prims["pad"] = -1
+    return prims
+
+
+def test_morton_keyed_tree_height_limit(gpu_ctx_factory):
+    """Codes that differ in ever lower bits give a comb-shaped radix tree.  Up to the supported height the library
+    equals the oracle; a higher tree is refused with PT_ERR_UNSUPPORTED (the traversal stacks are sized for 64
+    levels) and the context stays usable."""
+    flags = ptamd.PT_BUILD_MORTON_FULL | ptamd.PT_BUILD_TOPOLOGY_MORTON
+    ctx = gpu_ctx_factory()
+    heights = {}
+    for bits, dup in ((40, 3), (61, 16)):
+        prims = _single_bit_scene(bits, dup)
+        n = len(prims)
+        ob = orc.build_codes_topology(prims.view(orc.PRIM_RENDER), True)
+        heights[bits] = orc.tree_height(ob["tree"], n)
+        ctx.upload_primitives(prims)
+        if heights[bits] <= 64:
+            ctx.build(flags)
+            _same_tree(ctx.tree(), ob["tree"][:2 * n])
+        else:
+            with pytest.raises(ptamd.PtError) as e:
+                ctx.build(flags)
+            assert "higher than" in str(e.value)
+            ctx.build(ptamd.PT_BUILD_MORTON_FULL)                 # the reference's tree still builds
+            _same_tree(ctx.tree(), orc.build_full_codes(prims.view(orc.PRIM_RENDER))["tree"][:2 * n])
+    print("tree heights", heights)
+    assert heights[40] <= 64 < heights[61]
+
+
+def test_morton_keyed_tree_of_equal_codes(gpu_ctx_factory):
+    """All codes equal (n copies of one triangle): the keys are told apart by position only, which gives the
+    balanced tree over the positions; 3000 keys span three chunks of the refit.  Tree and a rendered frame equal
+    the oracle's."""
+    n, W, H = 3000, 64, 48
+    prims = np.zeros(n, dtype=ptamd.PRIM_RENDER)
+    prims["vertices"]["pos"][:, 0] = (40.0, 40.0, 50.0)
+    prims["vertices"]["pos"][:, 1] = (60.0, 40.0, 50.0)
+    prims["vertices"]["pos"][:, 2] = (50.0, 60.0, 50.0)
+    prims["vertices"]["normal"][:, :, 2] = 1.0
+    prims["pad"] = -1
+    ctx = gpu_ctx_factory()
+    cb, alb = _soup_setup(ctx, prims, W, H, ptamd.PT_BUILD_TOPOLOGY_MORTON)
+    ob = orc.build_codes_topology(prims.view(orc.PRIM_RENDER))
+    assert len(np.unique(ob["rays"]["morton_code"])) == 1
+    _same_tree(ctx.tree(), ob["tree"][:2 * n])
+    assert orc.tree_height(ob["tree"], n) == 12
+    ocam = orc.default_camera(**CAM); ocam.zfar = 1000.0
+    sc = orc.OracleScene(prims.view(orc.PRIM_RENDER), ob["tree"], cb, stack_size=120, max_segments=8)
+    gb = orc.primary(sc, ocam, W, H, alb)
+    d, nn, w = ctx.download_gbuffer()
+    assert np.array_equal(d, gb[0]) and np.array_equal(_bits(nn), _bits(gb[1])) and np.array_equal(_bits(w), _bits(gb[2]))
+    assert (gb[1][..., 3].view(np.int32) > 0).any()                  # the triangle is in view
+    ctx.set_detailed_counters(True)
+    seeds = ptamd.frame_seeds(1, 0, 1)
+    ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LINEAR)
+    acc = np.zeros((H, W, 4), np.float32)
+    c = orc.trace_frame_linear(sc, gb, 0, seeds[0], acc)
+    assert np.array_equal(_bits(ctx.linear_sum()), _bits(acc)) and ctx.counters() == c
