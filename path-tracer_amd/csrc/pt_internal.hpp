@@ -100,7 +100,7 @@ struct Knobs {
     int no_order = 0;                   // PTAMD_NO_ORDER: image order instead of most-expensive-first
     int chunk = 0;                      // PTAMD_CHUNK: frames per work item
     int print_sched = 0;                // PTAMD_PRINT_SCHED: scheduling statistics on stderr
-    int pair_max_mib = 4096;            // PTAMD_PAIR_MAX_MIB: largest node + left-child line array (0: never use it)
+    int pair_max_mib = 65536;           // PTAMD_PAIR_MAX_MIB: largest array of child lines (0: never use it)
 };
 
 struct pt_context {
@@ -138,7 +138,7 @@ struct pt_context {
     pt_TreeNode *d_tree = nullptr;    // 2n+1, allocated and filled by the first pt_download_tree after a build
     bool tree_exported = false;
     WideNode *d_wide = nullptr;       // n
-    float4 *d_pair = nullptr;         // 8 float4 per node (its record + its left child's), made by the first trace of a
+    float4 *d_pair = nullptr;         // 8 float4 per node (the records of its two children), made by the first trace of a
                                       // tree that stays in global memory
     size_t pair_cap = 0;
     bool pair_valid = false;

@@ -34,7 +34,7 @@ constexpr int POP = (int)0x80000000;
 
 struct SceneView {
     const WideNode *__restrict__ wide;
-    const float4 *__restrict__ pair;    // 8 float4 per internal node: its record and its left child's (k_pair_records), or null
+    const float4 *__restrict__ pair;    // 8 float4 per internal node: the records of its two children (k_pair_records), or null
     const TriIsect *__restrict__ tri;
     const TriShade *__restrict__ shade;
     const pt_CB_Radix *__restrict__ cb;
@@ -171,6 +171,18 @@ __device__ __forceinline__ bool traverse(const SceneView &sc, const Ray &ray, ui
             }
         }
     }
+}
+
+// A node's own record (the boxes of its two children) from the records of those children: a child's box is the union
+// of ITS children's boxes, taken with the refit's operations in the refit's operand order (left, right), so the bits
+// are the ones the build stored.  a = the left child's record, b = the right child's (a leaf child: its box twice).
+__device__ __forceinline__ void record_from_children(const float4 a0, const float4 a1, const float4 a2,
+                                                     const float4 b0, const float4 b1, const float4 b2,
+                                                     float4 &w0, float4 &w1, float4 &w2)
+{
+    w0 = make_float4(fminf(a0.x, a1.z), fminf(a0.y, a1.w), fminf(a0.z, a2.x), fmaxf(a0.w, a2.y));
+    w1 = make_float4(fmaxf(a1.x, a2.z), fmaxf(a1.y, a2.w), fminf(b0.x, b1.z), fminf(b0.y, b1.w));
+    w2 = make_float4(fminf(b0.z, b2.x), fmaxf(b0.w, b2.y), fmaxf(b1.x, b2.z), fmaxf(b1.y, b2.w));
 }
 
 // Material tables have PT_MAX_MATERIALS entries plus one all-zero entry: an id outside 0..15 (a
@@ -469,11 +481,12 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
     bool intersected = false;
     int hit_leaf = 0;
     float hit_bx = 0, hit_by = 0, hit_bz = 0;
-    // global-memory variant: the record of the current node's left child arrived in the same 128-byte line
-    // as the node's own (next0..2); `next_valid` says that the current node IS that left child
+    // global-memory variant with child lines (PAIR): the 128-byte line of a node holds the records of BOTH its children
+    // (the node's own record follows from them), so the node AND whichever child is visited next are expanded from one
+    // request.  next0..2 = the record of the child the lane went to; `next_valid` says that the current node is that child
     float4 next0 = make_float4(0, 0, 0, 0), next1 = next0, next2 = next0;
     bool next_valid = false;
-    int next_l = 0, next_r = 0;         // GEN + PAIR: the left child's own child ids
+    int next_l = 0, next_r = 0;         // GEN + PAIR: that child's own child ids
     // GEN: `pending` counts the stack entries; the deeper part of the stack of this lane
     uint2 *const gst = GEN ? gstack + ((size_t)blockIdx.x * nthreads + threadIdx.x) : nullptr;
     const size_t gstride = GEN ? (size_t)gridDim.x * nthreads : 0;
@@ -644,7 +657,8 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                 if (GEN) {
                     if (cur_k >= 1) {
                         float4 w0, w1, w2;
-                        int left, right;
+                        float4 a0 = next0, a1 = next1, a2 = next2, b0 = next0, b1 = next1, b2 = next2;
+                        int left, right, ll = 0, lr = 0, rl = 0, rr = 0;
                         if (!PAIR) {
                             const float4 *w = reinterpret_cast<const float4 *>(sc.wide + cur_id);
                             w0 = w[0]; w1 = w[1]; w2 = w[2];
@@ -653,13 +667,15 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                         } else if (next_valid) {
                             w0 = next0; w1 = next1; w2 = next2; left = next_l; right = next_r;
                         } else {
-                            // one 128-byte line: the node's boxes, its left child's boxes, the child ids of both
+                            // one 128-byte line: the records of both children and the child ids of all three nodes
                             const float4 *w = sc.pair + (size_t)cur_id * 8;
-                            w0 = w[0]; w1 = w[1]; w2 = w[2];
-                            next0 = w[3]; next1 = w[4]; next2 = w[5];
-                            const float4 ids = w[6];
+                            a0 = w[0]; a1 = w[1]; a2 = w[2];
+                            b0 = w[3]; b1 = w[4]; b2 = w[5];
+                            const float4 ids = w[6], idr = w[7];
                             left = __float_as_int(ids.x); right = __float_as_int(ids.y);
-                            next_l = __float_as_int(ids.z); next_r = __float_as_int(ids.w);
+                            ll = __float_as_int(ids.z); lr = __float_as_int(ids.w);
+                            rl = __float_as_int(idr.x); rr = __float_as_int(idr.y);
+                            record_from_children(a0, a1, a2, b0, b1, b2, w0, w1, w2);
                         }
                         const bool fetched_pair = PAIR && !next_valid;
                         const float lmn[3] = {w0.x, w0.y, w0.z}, lmx[3] = {w0.w, w1.x, w1.y};
@@ -685,11 +701,17 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                         if (!(hl || hr)) cur_k = K_POP;
                         else if (nxt < 0) { cur_k = 0; cur_s = ~nxt; }
                         else cur_id = nxt;                  // cur_k stays 1
-                        if (PAIR) next_valid = fetched_pair && go_left && left >= 0;
+                        if (PAIR) {
+                            // the record of the child the lane moved to came with this node's line
+                            next0 = go_left ? a0 : b0; next1 = go_left ? a1 : b1; next2 = go_left ? a2 : b2;
+                            next_l = go_left ? ll : rl; next_r = go_left ? lr : rr;
+                            next_valid = fetched_pair && (hl || hr) && nxt >= 0;
+                        }
                     }
                 } else
                 if (cur_k >= 1) {                       // only traversing lanes have cur_k >= K_POP
                     float4 w0, w1, w2;
+                    float4 a0 = next0, a1 = next1, a2 = next2, b0 = next0, b1 = next1, b2 = next2;
                     if (LDSN) {
                         const float4 *w = lds_nodes + __umul24((unsigned)cur_id, 3u);      // 24-bit multiply: full rate
                         w0 = w[0]; w1 = w[1]; w2 = w[2];
@@ -699,12 +721,13 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                     } else if (next_valid) {
                         w0 = next0; w1 = next1; w2 = next2;        // came with the parent's line: no fetch
                     } else {
-                        // one 128-byte line: this node's record and its left child's.  The memory system serves a
-                        // random 128-byte line at the rate of a random 64-byte one, so the left descent of every
-                        // other level costs no request of its own.
+                        // one 128-byte line: the records of both children.  The memory system serves a random 128-byte
+                        // line at the rate of a random 64-byte one, so the step from this node to either child costs
+                        // no request of its own.
                         const float4 *w = sc.pair + (size_t)cur_id * 8;
-                        w0 = w[0]; w1 = w[1]; w2 = w[2];
-                        next0 = w[3]; next1 = w[4]; next2 = w[5];
+                        a0 = w[0]; a1 = w[1]; a2 = w[2];
+                        b0 = w[3]; b1 = w[4]; b2 = w[5];
+                        record_from_children(a0, a1, a2, b0, b1, b2, w0, w1, w2);
                     }
                     const bool fetched_pair = PAIR && !next_valid;
                     const float lmn[3] = {w0.x, w0.y, w0.z}, lmx[3] = {w0.w, w1.x, w1.y};
@@ -737,7 +760,13 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                         cur_id = hl ? sr - 1 : sr;
                         cur_s = hl ? cur_s : sr;          // after a double miss only the bits above the pending levels matter
                     }
-                    if (PAIR) next_valid = fetched_pair && cur_k == k - 1 && cur_id == sr - 1 && k >= 2;
+                    if (PAIR) {
+                        // the lane moved to the left child (level k - 1) or to the right one: that child's record came
+                        // with this node's line
+                        const bool went_left = cur_id == sr - 1;
+                        next0 = went_left ? a0 : b0; next1 = went_left ? a1 : b1; next2 = went_left ? a2 : b2;
+                        next_valid = fetched_pair && cur_k >= 1;
+                    }
                 }
         };
         auto pop = [&]() {
@@ -1384,50 +1413,60 @@ __device__ __forceinline__ int node_level(int id, int n, int levels)
     return 32 - __clz(id ^ e);
 }
 
-// One 128-byte line per internal node for the traversal of trees that live in global memory: the node's own
-// record (both child boxes, 48 bytes) followed by its LEFT child's record when that child is an internal node.
-// 8 float4 per node; float4 3..5 of a level-1 node and 6..7 of every node are unused.
+// the record slot of a LEAF child in a child line: its box twice, so that the union the traversal takes is the box itself
+__device__ __forceinline__ void leaf_slot(float4 *__restrict__ d, const float *mn, const float *mx)
+{
+    d[0] = make_float4(mn[0], mn[1], mn[2], mx[0]);
+    d[1] = make_float4(mx[1], mx[2], mn[0], mn[1]);
+    d[2] = make_float4(mn[2], mx[0], mx[1], mx[2]);
+}
+
+// One 128-byte line per internal node for the traversal of trees that live in global memory: the records of the
+// node's LEFT and RIGHT child (48 bytes each; a leaf child: its box twice).  The node's own record is not stored: the
+// boxes of its children are the unions of the boxes in these two records.  8 float4 per node; 6..7 are unused here.
 __global__ __launch_bounds__(256) void k_pair_records(const WideNode *__restrict__ wide, int n, int levels, float4 *__restrict__ pair)
 {
-    // two threads per node: thread 0 copies the node's record, thread 1 its left child's
+    // two threads per node: thread 0 writes the left child's slot, thread 1 the right child's
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int id = (int)(t >> 1), half = (int)(t & 1);
     if (id >= n) return;
-    int src = id;
-    if (half) {
-        const int k = node_level(id, n, levels);
-        if (k < 2) return;
-        const int first = (id == 0 || !(id & 1)) ? id : id - (1 << k) + 1;      // first key of the node's range
-        src = first + (1 << (k - 1)) - 1;                                       // its left child, named by its last key
-    }
-    const float4 *s = reinterpret_cast<const float4 *>(&wide[src]);
+    const int k = node_level(id, n, levels);
+    const int first = (id == 0 || !(id & 1)) ? id : id - (1 << k) + 1;          // first key of the node's range
+    const int sr = first + (1 << (k - 1)), e = min(first + (1 << k) - 1, n);   // the right child's first key, the node's last
+    // closed form: the left child is a leaf at level 1 and else named by its last key; the right child is a leaf when
+    // its range is one key and else named by its first key
+    const bool leaf = half ? (sr == e) : (k == 1);
+    const int child = half ? sr : sr - 1;
     float4 *d = pair + (size_t)id * 8 + half * 3;
-    d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+    if (leaf) {
+        const WideNode &w = wide[id];
+        if (half) leaf_slot(d, w.rmin, w.rmax); else leaf_slot(d, w.lmin, w.lmax);
+    } else {
+        const float4 *s = reinterpret_cast<const float4 *>(&wide[child]);
+        d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+    }
 }
 
 // The same line for a tree with explicit child ids (PT_BUILD_TOPOLOGY_MORTON, n_nodes = n - 1): float4 6 holds the
-// node's child ids and its left child's.
+// node's child ids and its left child's, float4 7 the right child's.
 __global__ __launch_bounds__(256) void k_pair_records_ids(const WideNode *__restrict__ wide, int n_nodes, float4 *__restrict__ pair)
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int id = (int)(t >> 1), half = (int)(t & 1);
     if (id >= n_nodes) return;
-    const float4 own3 = reinterpret_cast<const float4 *>(&wide[id])[3];
-    const int left = __float_as_int(own3.x);
+    const WideNode &w = wide[id];
+    const int child = half ? w.right : w.left;
     float4 *d = pair + (size_t)id * 8;
-    if (!half) {
-        const float4 *s = reinterpret_cast<const float4 *>(&wide[id]);
-        d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
-        float4 ids = make_float4(own3.x, own3.y, 0.0f, 0.0f);
-        if (left >= 0) {
-            const float4 c3 = reinterpret_cast<const float4 *>(&wide[left])[3];
-            ids.z = c3.x; ids.w = c3.y;
-        }
-        d[6] = ids;
-    } else if (left >= 0) {
-        const float4 *s = reinterpret_cast<const float4 *>(&wide[left]);
-        d[3] = s[0]; d[4] = s[1]; d[5] = s[2];
+    float4 child_ids = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (child < 0) {
+        if (half) leaf_slot(d + 3, w.rmin, w.rmax); else leaf_slot(d, w.lmin, w.lmax);
+    } else {
+        const float4 *s = reinterpret_cast<const float4 *>(&wide[child]);
+        d[half * 3 + 0] = s[0]; d[half * 3 + 1] = s[1]; d[half * 3 + 2] = s[2];
+        child_ids = s[3];
     }
+    if (half) d[7] = make_float4(child_ids.x, child_ids.y, 0.0f, 0.0f);
+    else      d[6] = make_float4(__int_as_float(w.left), __int_as_float(w.right), child_ids.x, child_ids.y);
 }
 
 __global__ void k_root_box(const WideNode *__restrict__ wide, float *__restrict__ out6)
@@ -1563,13 +1602,12 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
         if (kn.max_threads >= 256) threads = (kn.max_threads / 64) * 64;
         lds_bytes = MAT_SLOTS * 64 + (size_t)levels * 4 * threads;
     }
-    // pair lines double the node array: past a few GiB the larger footprint (address translation) costs what the
-    // saved requests gain, so the largest scenes read the plain 64-byte records
-    // (a tree over the Morton codes keeps a subtree's records close together in memory: the lines pay up to four times that size)
-    const size_t pair_max_nodes = kn.pair_max_mib > 0 ? ((size_t)kn.pair_max_mib << 20) / 128 * (gen ? 4 : 1) : 0;
+    // child lines take twice the memory of the plain records; measured up to 100 M triangles (12.8 GB of lines) they pay
+    // at every size that does not fit in LDS (PTAMD_PAIR_MAX_MIB bounds the array; 0 = plain records)
+    const size_t pair_max_nodes = kn.pair_max_mib > 0 ? ((size_t)kn.pair_max_mib << 20) / 128 : 0;
     const bool use_pair = !lds_nodes && (size_t)ctx->n <= pair_max_nodes;
     if (use_pair && !ctx->pair_valid) {
-        // the 128-byte node + left-child lines of the global-memory traversal, made at the first trace after a build
+        // the 128-byte child lines of the global-memory traversal, made at the first trace after a build
         // (a build alone does not pay for them)
         if (ctx->pair_cap < (size_t)ctx->n) {
             PT_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -1,5 +1,5 @@
 """Render rate of device-generated soups of several sizes with the options of the largest configuration, with and
-without the node + left-child lines (PTAMD_PAIR_MAX_MIB=0 disables them): where the larger node array stops paying.
+without the 128-byte child lines (PTAMD_PAIR_MAX_MIB=0 disables them).
 usage: gpu_soup_sizes.py n1 n2 ...   (run once per setting of PTAMD_PAIR_MAX_MIB; NEAR=1: nearest child first;
 TOPO=1: PT_BUILD_TOPOLOGY_MORTON)"""
 import os, sys, time

@@ -56,8 +56,8 @@ def test_large_scene_option_set_against_the_oracle(gpu_ctx_factory, monkeypatch,
     """n = 200k (18 levels, node records 9.6 MB: global memory), full-resolution codes, stack 32, at most 8
     rays per path, 4 diffuse + 1 emissive material, cube scaled to 100 units (the triangle test rejects
     |det| <= 1e-4 on unnormalised edges, ray_tracing.hlsl:172).  Library == oracle with the same options, with the
-    128-byte node + left-child lines the traversal reads up to a few GiB of nodes, and with the plain 64-byte
-    records it reads beyond (PTAMD_PAIR_MAX_MIB, read when the context is created)."""
+    128-byte child lines the traversal reads (the records of both children of a node in one line) and with the plain
+    64-byte records (PTAMD_PAIR_MAX_MIB=0, read when the context is created)."""
     n, W, H = 200_000, 200, 150
     if not pair_lines:
         monkeypatch.setenv("PTAMD_PAIR_MAX_MIB", "0")
