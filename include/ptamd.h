@@ -289,7 +289,9 @@ int pt_reset_counters(pt_context *ctx);
  * most-expensive-first), PTAMD_CHUNK (frames per work item), PTAMD_PRINT_SCHED=1 (scheduling
  * statistics of the instrumented kernel on stderr at pt_get_counters), PTAMD_PAIR_MAX_MIB (trees that do not
  * fit in LDS are traversed through an array of 128-byte lines holding the records of a node's two children, made at
- * the first trace after a build, as long as that array stays below this size: 65536; 0 = always the plain records). */
+ * the first trace after a build, as long as that array stays below this size: 65536; 0 = always the plain records),
+ * PTAMD_GEN_LDS_ENTRIES (PT_BUILD_TOPOLOGY_MORTON trees: entries of each lane's traversal stack kept in LDS, the deeper
+ * ones live in global memory; default: as many as fit, 19 at 1024 threads). */
 
 /* device-side duration of the trace kernel of every launch since timing was enabled (or since the
  * last pt_get_trace_times): HIP events on the context's stream around the persistent trace kernel

@@ -31,6 +31,7 @@ static void read_knobs(Knobs &k)
     k.chunk = env_int("PTAMD_CHUNK", 0);
     k.print_sched = env_int("PTAMD_PRINT_SCHED", 0);
     k.pair_max_mib = env_int("PTAMD_PAIR_MAX_MIB", k.pair_max_mib);
+    k.gen_lds_entries = env_int("PTAMD_GEN_LDS_ENTRIES", 0);
 }
 
 static int bit_length_u(unsigned v) { return v ? 32 - __builtin_clz(v) : 0; }

@@ -100,6 +100,7 @@ struct Knobs {
     int no_order = 0;                   // PTAMD_NO_ORDER: image order instead of most-expensive-first
     int chunk = 0;                      // PTAMD_CHUNK: frames per work item
     int print_sched = 0;                // PTAMD_PRINT_SCHED: scheduling statistics on stderr
+    int gen_lds_entries = 0;            // PTAMD_GEN_LDS_ENTRIES: cap of the LDS part of the explicit traversal stack (0: what fits)
     int pair_max_mib = 65536;           // PTAMD_PAIR_MAX_MIB: largest array of child lines (0: never use it)
 };
 

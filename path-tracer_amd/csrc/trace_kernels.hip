@@ -1585,6 +1585,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
         if (kn.max_threads >= 256) threads = (kn.max_threads / 64) * 64;
         const int fit = (int)((160 * 1024 - MAT_SLOTS * 64) / (8 * (size_t)threads));
         levels = ctx->tree_height < fit ? ctx->tree_height : fit;
+        if (kn.gen_lds_entries >= 1 && kn.gen_lds_entries < levels) levels = kn.gen_lds_entries;
         lds_bytes = MAT_SLOTS * 64 + (size_t)levels * 8 * threads;
         const size_t deep = (size_t)(ctx->tree_height - levels) * ctx->num_cus * threads;
         if (ctx->gstack_cap < deep) {

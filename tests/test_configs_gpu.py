@@ -308,6 +308,10 @@ def test_morton_keyed_topology_against_the_oracle(gpu_ctx_factory, monkeypatch, 
     n, W, H = 200_000, 200, 150
     if not pair_lines:
         monkeypatch.setenv("PTAMD_PAIR_MAX_MIB", "0")
+    if not full:
+        # two stack entries per lane in LDS, the rest of every lane's stack in global memory: the path that trees
+        # higher than the LDS part take
+        monkeypatch.setenv("PTAMD_GEN_LDS_ENTRIES", "2")
     prims = make_soup(n, seed=777, dtype=ptamd.PRIM_RENDER)
     prims["vertices"]["pos"] *= np.float32(100.0)
     prims["matid"] = np.where(np.arange(n) % 16 == 0, 4, np.arange(n) % 4)
