@@ -32,6 +32,11 @@ static void read_knobs(Knobs &k)
     k.print_sched = env_int("PTAMD_PRINT_SCHED", 0);
     k.pair_max_mib = env_int("PTAMD_PAIR_MAX_MIB", k.pair_max_mib);
     k.gen_lds_entries = env_int("PTAMD_GEN_LDS_ENTRIES", 0);
+    k.dual = env_int("PTAMD_DUAL", k.dual);
+    k.dual_refill_t = env_int("PTAMD_DUAL_REFILL_T", k.dual_refill_t);
+    k.swap_t = env_int("PTAMD_SWAP_T", k.swap_t);
+    k.shade_t = env_int("PTAMD_SHADE_T", k.shade_t);
+    k.dual_leaf_t = env_int("PTAMD_DUAL_LEAF_T", k.dual_leaf_t);
 }
 
 static int bit_length_u(unsigned v) { return v ? 32 - __builtin_clz(v) : 0; }

@@ -344,7 +344,7 @@ constexpr int MAX_ITR = 5;   // ray_tracing.hlsl:245-247
 // Per lane the order of node visits, tests and random draws is exactly that of
 // the sequential loop, so results do not change.
 // ---------------------------------------------------------------------------
-struct Tuning { int refill_t, leaf_t; int itr_limit; };    // itr_limit: a path ends when itr reaches it (reference: MAX_ITR * 3)
+struct Tuning { int refill_t, leaf_t; int itr_limit; int swap_t, shade_t; };    // itr_limit: a path ends when itr reaches it (reference: MAX_ITR * 3)
 
 // ---------------------------------------------------------------------------
 // Path seeds of one launch: seed(pixel, frame) = rand_init(pixel id, g_random[0] of the frame)
@@ -848,6 +848,372 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                                 hit_bx = bx; hit_by = by; hit_bz = bz;
                                 current_t = t;
                                 hit_leaf = cur_s;          // the shading record is in leaf order too
+                                intersected = true;
+                            }
+                        }
+                    }
+                    cur_k = K_POP;
+                }
+            }
+            pop();
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (COUNT) sched[9] += (unsigned long long)((long long)__builtin_readcyclecounter() - t_trav);
+    }
+    flush_counters(cnt, counters, COUNT);
+    if (COUNT && lane == 0) {
+        for (int k = 0; k < 10; k++) atomicAdd(&counters->sched[k], sched[k]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_trace_dual: the persistent kernel for trees in LDS (reference visit order) with TWO paths per lane, two
+// frames of the lane's pixel.  One path owns the traversal slot; the other is PARKED in registers, either as a
+// ray that is ready to be traversed or as a finished ray that waits for shading.
+//   * When the traversed ray ends, the lane exchanges it for the parked ray (register moves), so a lane idles
+//     only when BOTH its paths wait for shading; in k_trace_persistent every finished ray idles until the next
+//     refill round.
+//   * A refill round shades the parked slots: all lanes that finished a ray since the last round, not only
+//     the lanes that happen to be idle, run the (long) shading code together.
+// Per path the sequence of random draws, tests and arithmetic is the sequential loop's; the two frames of a
+// lane are independent paths with their own seeds and sample slots, so results do not change.
+// ---------------------------------------------------------------------------
+constexpr int K_EMPTY = -4;                              // holds an item, no path in the traversal slot
+// parked slot (even = a refill round has to serve it): P_START: free, the item has frames left; P_READY: a ray past the
+// root test; P_DONE: a finished ray; P_NONE: free, no frames left
+constexpr int P_START = 0, P_READY = 1, P_DONE = 2, P_NONE = 3;
+
+__device__ __forceinline__ void lane_swap(float &a, float &b) { const float t = a; a = b; b = t; }
+
+template <bool COUNT>
+__global__ __launch_bounds__(1024) void k_trace_dual(SceneView sc, const TriIsect *__restrict__ tri_sorted, int levels,
+                                              unsigned n_slots,
+                                              const uint8_t *__restrict__ diffuse_tex,
+                                              const float4 *__restrict__ normal_tex,
+                                              const float4 *__restrict__ world_tex,
+                                              uint32_t first_frame, uint32_t count,
+                                              float4 *__restrict__ samples, DevCounters *__restrict__ counters,
+                                              unsigned *__restrict__ work_counter,
+                                              const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
+                                              uint32_t chunk, Tuning tune)
+{
+    // LDS as in k_trace_persistent<LDSN = true>: node records, materials, material quotients, one float per level and lane
+    extern __shared__ __attribute__((aligned(16))) float4 lds_nodes[];
+    const int n = sc.n;
+    const int nthreads = blockDim.x;
+    float4 *lds_mats = lds_nodes + 3 * n;
+    float4 *lds_matq = lds_mats + 3 * MAT_SLOTS;
+    float *stack = reinterpret_cast<float *>(lds_matq + MAT_SLOTS) + threadIdx.x;   // level L at stack[(L-1) * nthreads]
+    for (int i = threadIdx.x; i < 3 * n; i += nthreads) {
+        const int node = i / 3, part = i - 3 * node;
+        lds_nodes[i] = reinterpret_cast<const float4 *>(&sc.wide[node])[part];
+    }
+    if (threadIdx.x < 3 * MAT_SLOTS) lds_mats[threadIdx.x] = reinterpret_cast<const float4 *>(sc.cb->mats)[threadIdx.x];
+    if (threadIdx.x < MAT_SLOTS) {
+        const float4 *mp = reinterpret_cast<const float4 *>(sc.cb->mats) + 3 * threadIdx.x;
+        lds_matq[threadIdx.x] = material_quotients(mp[0], mp[1], mp[2]);
+    }
+    __syncthreads();
+
+    // STARVE_T: lanes with nothing to traverse in either slot; SHADE_T: parked slots waiting for a refill round;
+    // SWAP_T: lanes whose ray ended while a parked ray is ready
+    const int STARVE_T = tune.refill_t, SHADE_T = tune.shade_t, LEAF_T = tune.leaf_t, ITR_LIMIT = tune.itr_limit, SWAP_T = tune.swap_t;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const unsigned chunks = (count + chunk - 1) / chunk;
+    const unsigned total_items = n_slots * chunks;
+    const float4 *mats = lds_mats;
+    const pt_f3 g_pos = pt_mk3(sc.cb->pos.v[0], sc.cb->pos.v[1], sc.cb->pos.v[2]);
+    const float root_mn[3] = {sc.root[0], sc.root[1], sc.root[2]}, root_mx[3] = {sc.root[3], sc.root[4], sc.root[5]};
+    const float T_MIN = PT_EPSILON, T_MAX = 10000;
+    LaneCounters cnt;
+    unsigned long long sched[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    unsigned q_next = 0, q_end = 0;
+    bool exhausted = false;
+    unsigned long long dead_mask = 0;   // lanes without an item after the queue ran dry
+
+    // per-item state
+    unsigned px = 0;
+    int matid0 = 0;
+    pt_f3 hit_pos = pt_mk3(0, 0, 0), multi0 = pt_mk3(0, 0, 0), view0 = pt_mk3(0, 0, 0), normal0 = pt_mk3(0, 0, 0);
+    uint32_t f = 0, f_end = 0;          // next local frame of the item that has no path yet, one past the item's last
+    uint32_t work_start = 0, iterations = 0;
+    // the lane's two paths (seed, bounce count, local frame, throughput); path `act` owns the traversal slot, the other
+    // one the parked slot.  Only the shading code reads or writes them.
+    uint32_t sd0 = 0, sd1 = 0, fl0 = 0, fl1 = 0;
+    int it0 = 1, it1 = 1, act = 0;
+    pt_f3 mu0 = pt_mk3(0, 0, 0), mu1 = mu0;
+    // traversal slot: cur_k >= K_POP: traversing; K_IDLE: its ray is finished, the result is still here; K_EMPTY / K_NOITEM: no path
+    int cur_k = K_NOITEM, cur_s = 0, cur_id = 0;
+    unsigned pending = 0;
+    pt_f3 ro = pt_mk3(0, 0, 0), rd = pt_mk3(0, 0, 1), inv = pt_mk3(1, 1, 1);
+    float current_t = 0;
+    bool intersected = false;
+    int hit_leaf = 0;
+    float hit_bx = 0, hit_by = 0;
+    // parked slot.  p_q: P_READY: 1 / direction; P_DONE: {leaf key of the hit or -1 (bits), barycentric x, y}
+    int p_state = P_NONE;
+    pt_f3 p_o = pt_mk3(0, 0, 0), p_d = pt_mk3(0, 0, 1);
+    float p_q0 = 0, p_q1 = 0, p_q2 = 0;
+
+    auto emit = [&](const pt_f3 &color, uint32_t fl) {
+        samples[(size_t)px * count + fl] = make_float4(color.x, color.y, color.z, 1.0f);
+    };
+    // The finished ray of the traversal slot (if any) moves to the parked slot, its origin advanced to the hit point
+    // (ray_tracing.hlsl:376); the parked ray (if any) moves to the traversal slot.  For lanes that are not traversing and
+    // whose parked slot holds a ray (`take`) or is free.
+    auto exchange = [&](bool take) {
+        const bool done = cur_k == K_IDLE;
+        if (done && intersected) ro = pt_add3(ro, pt_scale3(rd, current_t));
+        inv.x = __int_as_float(intersected ? hit_leaf : -1); inv.y = hit_bx; inv.z = hit_by;      // the outgoing p_q
+        lane_swap(ro.x, p_o.x); lane_swap(ro.y, p_o.y); lane_swap(ro.z, p_o.z);
+        lane_swap(rd.x, p_d.x); lane_swap(rd.y, p_d.y); lane_swap(rd.z, p_d.z);
+        lane_swap(inv.x, p_q0); lane_swap(inv.y, p_q1); lane_swap(inv.z, p_q2);
+        act ^= 1;
+        p_state = done ? P_DONE : (f < f_end ? P_START : P_NONE);
+        if (take) {
+            current_t = T_MAX; intersected = false; pending = 0;
+            cur_k = levels; cur_s = 0; cur_id = 0;
+        } else {
+            cur_k = K_EMPTY;
+        }
+    };
+
+    for (;;) {
+        {
+            const bool idle = cur_k == K_IDLE || cur_k == K_EMPTY, take = p_state == P_READY;
+            if (idle && take) exchange(true);
+        }
+        const unsigned long long trav_mask = ballot64(cur_k >= K_POP);
+        const unsigned long long shade_mask = ballot64((p_state & 1) == 0);
+        const unsigned long long starved_mask = ~trav_mask & ~dead_mask;      // after the exchange: idle lanes have no ready ray
+        if (starved_mask == 0 && trav_mask == 0) break;
+        // ------------------------------------------------------------ refill
+        // (every starved lane needs the round: an item, its finished ray parked and shaded, or its item closed)
+        if ((shade_mask | starved_mask) != 0 &&
+            (__popcll(starved_mask) >= STARVE_T || __popcll(shade_mask) >= SHADE_T || trav_mask == 0)) {
+            if (COUNT) sched[5]++;
+            const long long t_refill = COUNT ? (long long)__builtin_readcyclecounter() : 0;
+            for (int pass = 0; pass < 2; pass++) {
+                // ---- take new pixels
+                bool want = cur_k == K_NOITEM && !exhausted;
+                unsigned long long wm = ballot64(want);
+                while (wm != 0) {
+                    if (q_next == q_end) {
+                        unsigned base = 0;
+                        if (lane == 0) base = atomicAdd(work_counter, 64u);
+                        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                        if (base >= total_items) { exhausted = true; break; }
+                        q_next = base;
+                        q_end = min(base + 64u, total_items);
+                    }
+                    const unsigned rank = (unsigned)__popcll(wm & lt_mask);
+                    const unsigned avail = q_end - q_next;
+                    if (want && rank < avail) {
+                        const unsigned item = q_next + rank, slot = item / chunks;
+                        px = order ? order[slot] : slot;
+                        f = (item - slot * chunks) * chunk;
+                        f_end = min(f + chunk, count);
+                        work_start = iterations;
+                        const uchar4 dif8 = reinterpret_cast<const uchar4 *>(diffuse_tex)[px];
+                        const float4 nrm4 = normal_tex[px];
+                        const float4 pos4 = world_tex[px];
+                        matid0 = mat_slot(__float_as_int(nrm4.w) - 1);  // asint(normal.w) - 1
+                        if (__float_as_int(nrm4.w) <= 0) {
+                            // ray_tracing.hlsl:361-362: black, but still accumulated every frame
+                            for (uint32_t k = f; k < f_end; k++) { cnt.paths++; emit(pt_mk3(0, 0, 0), k); }
+                        } else {
+                            hit_pos = pt_mk3(pos4.x, pos4.y, pos4.z);
+                            multi0 = pt_mk3(dif8.x / 255.0f, dif8.y / 255.0f, dif8.z / 255.0f);
+                            if (mats[3 * matid0].y > 1) multi0 = pt_mk3(1, 1, 1);
+                            view0 = pt_normalize3(pt_sub3(hit_pos, g_pos));
+                            normal0 = pt_normalize3(pt_mk3(nrm4.x, nrm4.y, nrm4.z));
+                            cur_k = K_EMPTY;
+                            p_state = P_START;              // an item has at least one frame
+                            want = false;
+                        }
+                    }
+                    q_next += min((unsigned)__popcll(wm), avail);
+                    wm = ballot64(want);
+                }
+                // ---- a finished ray whose lane has a free parked slot moves there to be shaded in this round
+                if (cur_k == K_IDLE && (p_state == P_START || p_state == P_NONE)) exchange(false);
+                // ---- shade the parked slots: finished rays continue or end their path, free slots start the next
+                // frame's path; ONE pass of the shading code for all of them
+                if ((p_state & 1) == 0) {
+                    // the parked path is the one that does not own the traversal slot
+                    uint32_t p_seed = act ? sd0 : sd1, p_fl = act ? fl0 : fl1;
+                    int p_itr = act ? it0 : it1;
+                    pt_f3 p_multi = pt_mk3(act ? mu0.x : mu1.x, act ? mu0.y : mu1.y, act ? mu0.z : mu1.z);
+                    pt_f3 direction;
+                    bool cont = false, bounce = false;
+                    pt_f3 b_view = view0, b_normal = normal0;
+                    int b_mat = matid0;
+                    if (p_state == P_DONE) {
+                        // back from intersect() (ray_tracing.hlsl:372-395); p_o is the hit point already
+                        bool ended = true;
+                        const int leaf = __float_as_int(p_q0);
+                        if (leaf >= 0) {
+                            p_itr++;
+                            const float4 *shp = reinterpret_cast<const float4 *>(&sc.shade[leaf]);
+                            const float4 s0 = shp[0], s1 = shp[1], s2 = shp[2];
+                            ended = false;
+                            if (p_itr > MAX_ITR) {
+                                const float pr = pt_max(pt_max(p_multi.x, p_multi.y), p_multi.z);
+                                if (pr > rand_next(p_seed)) p_multi = pt_scale3(p_multi, 1 / pr);
+                                else ended = true;
+                            }
+                            if (!ended && p_itr >= ITR_LIMIT) ended = true;
+                            if (!ended) {
+                                const float bx = p_q1, by = p_q2, bz = 1 - bx - by;
+                                const pt_f3 A = pt_mk3(s0.x, s0.y, s0.z), B = pt_mk3(s1.x, s1.y, s1.z), C = pt_mk3(s2.x, s2.y, s2.z);
+                                b_normal = pt_add3(pt_add3(pt_scale3(A, bz), pt_scale3(B, bx)), pt_scale3(C, by));
+                                b_view = p_d;
+                                b_mat = __float_as_int(s0.w);
+                                bounce = true;
+                            }
+                        }
+                        if (ended) {
+                            emit(pt_mk3(0, 0, 0), p_fl);
+                            p_state = f < f_end ? P_START : P_NONE;
+                        }
+                    }
+                    if (p_state == P_START) {
+                        // new path of frame f (ray_tracing.hlsl:348-370, 410)
+                        cnt.paths++;
+                        p_seed = __float_as_uint(samples[(size_t)px * count + f].w);
+                        p_multi = multi0;
+                        p_itr = 1;
+                        p_o = hit_pos;
+                        p_fl = f;
+                        f++;
+                        p_state = P_DONE;           // a path is in the slot (the outcome below decides its state)
+                        bounce = true;
+                    }
+                    if (bounce) {
+                        if (get_bounce(mats, lds_matq, first_frame + p_fl, b_view, b_normal, b_mat, p_multi, direction, p_seed)) {
+                            cont = true;
+                        } else {
+                            emit(p_multi, p_fl);
+                            p_state = f < f_end ? P_START : P_NONE;
+                        }
+                    }
+                    if (cont) {
+                        // intersect() starts with the root's own box test (ray_tracing.hlsl:191-214); a ray that misses
+                        // the root is a finished ray without a hit
+                        p_d = direction;
+                        const pt_f3 pinv = pt_mk3(1.0f / direction.x, 1.0f / direction.y, 1.0f / direction.z);
+                        cnt.rays++;
+                        if (COUNT) { cnt.node_visits++; cnt.box_tests++; }
+                        float t_entry;
+                        if (slab(root_mn, root_mx, p_o, pinv, t_entry) && t_entry <= T_MAX) {
+                            p_state = P_READY;
+                            p_q0 = pinv.x; p_q1 = pinv.y; p_q2 = pinv.z;
+                        } else {
+                            p_state = P_DONE;
+                            p_q0 = __int_as_float(-1);
+                        }
+                    }
+                    if (act) { sd0 = p_seed; fl0 = p_fl; it0 = p_itr; mu0 = p_multi; }
+                    else     { sd1 = p_seed; fl1 = p_fl; it1 = p_itr; mu1 = p_multi; }
+                }
+                if ((cur_k == K_IDLE || cur_k == K_EMPTY) && p_state == P_READY) exchange(true);
+                // ---- items whose frames are all done
+                if (cur_k == K_EMPTY && p_state == P_NONE) {
+                    if (pixel_work && iterations != work_start) atomicAdd(&pixel_work[px], iterations - work_start);
+                    cur_k = K_NOITEM;
+                }
+                if (exhausted || ballot64(cur_k == K_NOITEM) == 0) break;
+            }
+            if (exhausted) dead_mask = ballot64(cur_k == K_NOITEM);
+            if (COUNT) sched[8] += (unsigned long long)((long long)__builtin_readcyclecounter() - t_refill);
+        }
+        __builtin_amdgcn_s_setprio(1);
+        const long long t_trav = COUNT ? (long long)__builtin_readcyclecounter() : 0;
+        // --------------------------------------------------------- traversal (as k_trace_persistent, tree in LDS)
+        auto expand = [&]() {
+                if (COUNT) {
+                    sched[0]++;
+                    sched[1] += __popcll(ballot64(cur_k >= 1));
+                    sched[4] += __popcll(ballot64(cur_k == 0));
+                    sched[6] += __popcll(ballot64(cur_k == K_IDLE || cur_k == K_EMPTY));
+                    sched[7] += __popcll(ballot64(cur_k == K_NOITEM));
+                }
+                if (cur_k >= 1) {
+                    const float4 *w = lds_nodes + __umul24((unsigned)cur_id, 3u);
+                    const float4 w0 = w[0], w1 = w[1], w2 = w[2];
+                    const float lmn[3] = {w0.x, w0.y, w0.z}, lmx[3] = {w0.w, w1.x, w1.y};
+                    const float rmn[3] = {w1.z, w1.w, w2.x}, rmx[3] = {w2.y, w2.z, w2.w};
+                    float tl, tr;
+                    const bool hl = slab(lmn, lmx, ro, inv, tl) && tl <= current_t;
+                    const bool hr = slab(rmn, rmx, ro, inv, tr) && tr <= current_t;
+                    if (COUNT) { cnt.node_visits += 2; cnt.box_tests += 2; }
+                    const int k = cur_k, half = 1 << (k - 1);
+                    const int sr = cur_s + half, e = min(sr + half - 1, n);
+                    const int kr = 32 - __clz(sr ^ e);
+                    if (hl && hr) { stack[__umul24((unsigned)(k - 1), (unsigned)nthreads)] = tr; pending |= 1u << k; }
+                    cur_k = hl ? k - 1 : (hr ? kr : K_POP);
+                    cur_id = hl ? sr - 1 : sr;
+                    cur_s = hl ? cur_s : sr;
+                }
+        };
+        auto pop = [&]() {
+                if (cur_k == K_POP) {
+                    if (pending == 0) {
+                        cur_k = K_IDLE;
+                    } else {
+                        const int L = __ffs((int)pending) - 1;
+                        pending &= pending - 1;
+                        const float t_entry = stack[__umul24((unsigned)(L - 1), (unsigned)nthreads)];
+                        if (t_entry <= current_t) {
+                            const int sa = (cur_s >> L) << L, half = 1 << (L - 1);
+                            const int sr = sa + half, e = min(sa + 2 * half - 1, n);
+                            cur_k = 32 - __clz(sr ^ e);
+                            cur_s = sr;
+                            cur_id = sr;
+                        }
+                    }
+                }
+        };
+        for (;;) {
+            const unsigned long long tm = ballot64(cur_k >= K_POP);
+            if (tm == 0) break;
+            const unsigned long long ready = ballot64(p_state == P_READY);
+            if (__popcll(~tm & ~ready & ~dead_mask) >= STARVE_T) break;
+            if (__popcll(ballot64((p_state & 1) == 0)) >= SHADE_T) break;
+            if (__popcll(~tm & ready) >= SWAP_T) {
+                if ((cur_k == K_IDLE || cur_k == K_EMPTY) && p_state == P_READY) exchange(true);
+            }
+            iterations += EXPANSIONS;
+#pragma unroll
+            for (int u = 0; u < EXPANSIONS - 1; u++) { expand(); pop(); }
+            expand();
+            const bool at_leaf = cur_k == 0;
+            const unsigned long long leaf_mask = ballot64(at_leaf);
+            if (leaf_mask != 0 && (__popcll(leaf_mask) >= LEAF_T || ballot64(cur_k >= 1) == 0)) {
+                if (COUNT) { sched[2]++; sched[3] += __popcll(leaf_mask); }
+                if (at_leaf) {
+                    const float4 *tp = reinterpret_cast<const float4 *>(&tri_sorted[cur_s]);
+                    const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    if (COUNT) cnt.tri_tests++;
+                    // ray_tracing.hlsl:167-189
+                    const pt_f3 a = pt_mk3(t0.x, t0.y, t0.z), e_1 = pt_mk3(t1.x, t1.y, t1.z), e_2 = pt_mk3(t2.x, t2.y, t2.z);
+                    const pt_f3 q = pt_cross3(rd, e_2);
+                    const float a1 = pt_dot3(e_1, q);
+                    if (!(fabsf(a1) <= PT_EPSILON)) {
+                        const pt_f3 oa = pt_sub3(ro, a);
+                        const pt_f3 s = pt_mk3(oa.x / a1, oa.y / a1, oa.z / a1);
+                        const pt_f3 r = pt_cross3(s, e_1);
+                        const float t = pt_dot3(e_2, r);
+                        const float bx = pt_dot3(s, q);
+                        const float by = pt_dot3(r, rd);
+                        const float bz = 1 - bx - by;
+                        if (bx >= -PT_EPSILON && by >= -PT_EPSILON && bz >= -PT_EPSILON && t >= PT_EPSILON) {
+                            if (current_t > t && t > T_MIN) {
+                                hit_bx = bx; hit_by = by;
+                                current_t = t;
+                                hit_leaf = cur_s;
                                 intersected = true;
                             }
                         }
@@ -1564,7 +1930,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
     SceneView sv;
     if (int rc = make_view(ctx, sv)) return rc;
     const Knobs &kn = ctx->knobs;
-    Tuning tune = {kn.refill_t, kn.leaf_t, ctx->itr_limit};
+    Tuning tune = {kn.refill_t, kn.leaf_t, ctx->itr_limit, kn.swap_t, kn.shade_t};
     const bool lin = (mode == PT_ACCUM_LINEAR);
     const size_t npix = (size_t)ctx->W * ctx->H;
     int levels = 0;
@@ -1691,7 +2057,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             PathRec *queue[2] = {static_cast<PathRec *>(ctx->d_wf_queue[0]), static_cast<PathRec *>(ctx->d_wf_queue[1])};
             HitRec *hits = static_cast<HitRec *>(ctx->d_wf_hits);
             const dim3 fgrid((unsigned)ctx->num_cus * 8u), sgrid(32, WF_SEGS);
-            Tuning wt = {kn.wf_refill_t, kn.wf_leaf_t, ctx->itr_limit};
+            Tuning wt = {kn.wf_refill_t, kn.wf_leaf_t, ctx->itr_limit, kn.swap_t, kn.shade_t};
             if (int rc = ensure_lds_limit(ctx, 8, &k_wf_extend<false>, lds_bytes)) return rc;
             if (int rc = ensure_lds_limit(ctx, 9, &k_wf_extend<true>, lds_bytes)) return rc;
             if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream));
@@ -1744,7 +2110,20 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
                 (uint32_t)chunk, tune); } while (0)
             // slot of the variant in ctx->lds_attr: COUNT, LDSN, NEAR as bits; + 10 with pair lines, + 16 / + 22 for trees with
             // explicit child ids (without / with pair lines); 8, 9: wavefront; 28, 29: the per-ray kernels
-            if (near_first) {
+            if (lds_nodes && !near_first && kn.dual) {
+                // two paths per lane (k_trace_dual): slots 30, 31
+                Tuning dt = tune;
+                dt.refill_t = kn.dual_refill_t;
+                dt.leaf_t = kn.dual_leaf_t;
+#define PT_LAUNCH_DUAL(SLOT, C) do { \
+                if (int rc_ = ensure_lds_limit(ctx, SLOT, &k_trace_dual<C>, lds_bytes)) return rc_; \
+                if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream)); \
+                hipLaunchKernelGGL((k_trace_dual<C>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
+                    n_slots, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, ctx->d_samples, ctx->d_counters, ctx->d_work, \
+                    order, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, (uint32_t)chunk, dt); } while (0)
+                if (ctx->detailed) PT_LAUNCH_DUAL(31, true); else PT_LAUNCH_DUAL(30, false);
+#undef PT_LAUNCH_DUAL
+            } else if (near_first) {
                 if (lds_nodes) { if (ctx->detailed) PT_LAUNCH(7, true, true, true); else PT_LAUNCH(6, false, true, true); }
                 else           { if (ctx->detailed) PT_LAUNCH_G(5, true, true); else PT_LAUNCH_G(4, false, true); }
             } else {
