@@ -248,15 +248,17 @@ def cpu_baseline(g, W, H, budget_s=10.0, max_frames=32):
 
 
 def trace_roofline_scene(kern_avg_ms, rays_per_launch, bytes_per_ray, launches_per_step, profile_applies=True):
-    """Roofline of k_trace_persistent with the tree in LDS.  The kernel is bound by vector-instruction issue:
+    """Roofline of the trace kernel with the tree in LDS.  The kernel is bound by vector-instruction issue:
     `achieved` = vector wave-instructions per launch (hardware counter SQ_INSTS_VALU of the committed profile,
     taken on this same launch shape) over the launch duration measured HERE with HIP events; `peak` = one wave64
     instruction per 2 clocks per SIMD.  The algorithmic traversal bytes are served by LDS and L1/L2 and reported
     as such, not as an HBM fraction."""
     prof = load_profile(PROFILE_TRACE)
-    k = (prof or {}).get("k_trace_persistent")
+    # the kernel the library runs for trees in LDS: two paths per lane (k_trace_dual) unless PTAMD_DUAL=0
+    kernel = "k_trace_persistent" if os.environ.get("PTAMD_DUAL") == "0" else "k_trace_dual"
+    k = (prof or {}).get(kernel)
     on_chip = rays_per_launch * bytes_per_ray / (kern_avg_ms * 1e-3) / 1e9
-    out = {"bound": "valu", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GINST, "kernel": "k_trace_persistent",
+    out = {"bound": "valu", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GINST, "kernel": kernel,
            "launch_ms_avg": kern_avg_ms, "launches_per_step": launches_per_step,
            "algorithmic_bytes_served_on_chip_GBps": on_chip,
            "peak_note": f"{SIMDS} SIMDs x {CLOCK_GHZ} GHz / 2 clocks per wave64 instruction"}

@@ -12,7 +12,7 @@ for f in glob.glob(os.path.join(src, "*", "**", "*counter_collection.csv"), recu
         name = r["Kernel_Name"]
         m = re.search(r"(k_\w+)", name)
         k = m.group(1) if m else name.replace("void ", "").split("(")[0].strip()
-        if k in ("k_trace_persistent", "k_wf_extend") and (k + "<true") in name:
+        if k in ("k_trace_persistent", "k_trace_dual", "k_wf_extend") and (k + "<true") in name:
             k += "<detailed>"
         if k == "k_refit_low" and "k_refit_low<true" in name:
             k += "<pack>"          # the default build: the refit also writes the trace kernels' leaf records
