@@ -33,6 +33,7 @@ static void read_knobs(Knobs &k)
     k.pair_max_mib = env_int("PTAMD_PAIR_MAX_MIB", k.pair_max_mib);
     k.gen_lds_entries = env_int("PTAMD_GEN_LDS_ENTRIES", 0);
     k.dual = env_int("PTAMD_DUAL", k.dual);
+    k.dual_min_chunk = env_int("PTAMD_DUAL_MIN_CHUNK", k.dual_min_chunk);
     k.dual_refill_t = env_int("PTAMD_DUAL_REFILL_T", k.dual_refill_t);
     k.swap_t = env_int("PTAMD_SWAP_T", k.swap_t);
     k.shade_t = env_int("PTAMD_SHADE_T", k.shade_t);

@@ -2110,8 +2110,10 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
                 (uint32_t)chunk, tune); } while (0)
             // slot of the variant in ctx->lds_attr: COUNT, LDSN, NEAR as bits; + 10 with pair lines, + 16 / + 22 for trees with
             // explicit child ids (without / with pair lines); 8, 9: wavefront; 28, 29: the per-ray kernels
-            if (lds_nodes && !near_first && kn.dual) {
-                // two paths per lane (k_trace_dual): slots 30, 31
+            // two paths per lane need items of several frames (the two paths are two frames of one pixel): short launches,
+            // whose items are one or two frames, run the single-path kernel
+            if (lds_nodes && !near_first && kn.dual && chunk >= (unsigned long long)kn.dual_min_chunk) {
+                // k_trace_dual: slots 30, 31
                 Tuning dt = tune;
                 dt.refill_t = kn.dual_refill_t;
                 dt.leaf_t = kn.dual_leaf_t;

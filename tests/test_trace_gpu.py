@@ -45,18 +45,27 @@ def test_gbuffer_bit_exact(gpu_ctx_factory, golden, scene):
                           kd_override=[list(m[0:3]) for m in golden[scene]["mat_table"]] + [[0, 0, 0]] * (16 - len(golden[scene]["mat_table"]))))
 
 
-SCHEDULES = [ptamd.PT_SCHEDULE_PERSISTENT, ptamd.PT_SCHEDULE_WAVEFRONT]
+# the persistent schedule has two kernels for trees in LDS: one path per lane (short launches: items of one or two
+# frames) and two paths per lane (items of four frames or more); "dual" forces the second one onto these small cases
+SCHEDULES = [ptamd.PT_SCHEDULE_PERSISTENT, ptamd.PT_SCHEDULE_WAVEFRONT, "dual"]
+
+
+def _ctx_with_schedule(gpu_ctx_factory, monkeypatch, schedule):
+    if schedule == "dual":
+        monkeypatch.setenv("PTAMD_DUAL_MIN_CHUNK", "1")       # knobs are read when the context is created
+    ctx = gpu_ctx_factory()
+    ctx.set_trace_schedule(ptamd.PT_SCHEDULE_PERSISTENT if schedule == "dual" else schedule)
+    return ctx
 
 
 @pytest.mark.parametrize("schedule", SCHEDULES)
 @pytest.mark.parametrize("scene", SCENES)
-def test_frames_bit_exact_literal(gpu_ctx_factory, golden, scene, schedule):
+def test_frames_bit_exact_literal(gpu_ctx_factory, golden, scene, schedule, monkeypatch):
     """pt_trace one frame at a time (the reference's run loop), then a multi-frame launch that
     must continue the same recurrence; images, display bytes and counters equal the oracle's,
     whichever way the launch schedules its paths."""
     W, H = 160, 136
-    ctx = gpu_ctx_factory()
-    ctx.set_trace_schedule(schedule)
+    ctx = _ctx_with_schedule(gpu_ctx_factory, monkeypatch, schedule)
     sc, gb, _ = _setup(ctx, golden[scene], W, H)
     ctx.set_detailed_counters(True)
     seeds = ptamd.frame_seeds(1, 0, 7)
@@ -83,13 +92,12 @@ def test_frames_bit_exact_literal(gpu_ctx_factory, golden, scene, schedule):
 
 @pytest.mark.parametrize("schedule", SCHEDULES)
 @pytest.mark.parametrize("segments", [1, 3, 8, 14])
-def test_max_segments_bit_exact(gpu_ctx_factory, golden, schedule, segments):
+def test_max_segments_bit_exact(gpu_ctx_factory, golden, schedule, segments, monkeypatch):
     """pt_set_max_segments (the depth cap of the large synthetic configuration): paths end after that many
     rays, in the library and in the oracle alike; 14 is the reference's own limit."""
     W, H = 96, 80
     g = golden["scene04"]
-    ctx = gpu_ctx_factory()
-    ctx.set_trace_schedule(schedule)
+    ctx = _ctx_with_schedule(gpu_ctx_factory, monkeypatch, schedule)
     _, gb, _ = _setup(ctx, g, W, H)
     ctx.set_max_segments(segments)
     ctx.set_detailed_counters(True)
@@ -114,12 +122,11 @@ def test_max_segments_bit_exact(gpu_ctx_factory, golden, schedule, segments):
 
 @pytest.mark.parametrize("schedule", SCHEDULES)
 @pytest.mark.parametrize("scene", ["scene01", "scene04"])
-def test_frames_bit_exact_linear_and_late_frames(gpu_ctx_factory, golden, scene, schedule):
+def test_frames_bit_exact_linear_and_late_frames(gpu_ctx_factory, golden, scene, schedule, monkeypatch):
     """Linear-sum mode, starting at a late frame index so that all stratification bits of
     framecount (ray_tracing.hlsl:306-307,325-326) are exercised."""
     W, H, first, N = 120, 104, 1000, 34
-    ctx = gpu_ctx_factory()
-    ctx.set_trace_schedule(schedule)
+    ctx = _ctx_with_schedule(gpu_ctx_factory, monkeypatch, schedule)
     sc, gb, _ = _setup(ctx, golden[scene], W, H)
     seeds = ptamd.frame_seeds(1, first, N)
     ctx.trace_frames(first, seeds, ptamd.PT_ACCUM_LINEAR)
@@ -217,7 +224,7 @@ def test_soup_scene_with_all_material_kinds(gpu_ctx_factory):
 
 @pytest.mark.parametrize("schedule", SCHEDULES)
 @pytest.mark.parametrize("n,W,H", [(1, 7, 5), (2, 64, 1), (3, 1, 1), (5, 65, 3), (64, 33, 31)])
-def test_tiny_scenes_and_images(gpu_ctx_factory, n, W, H, schedule):
+def test_tiny_scenes_and_images(gpu_ctx_factory, n, W, H, schedule, monkeypatch):
     """Smallest trees (one triangle: the root's right child is the out-of-range leaf) and images
     smaller than a wave, narrower than a tile, of one pixel."""
     rng = np.random.default_rng(n)
@@ -228,8 +235,7 @@ def test_tiny_scenes_and_images(gpu_ctx_factory, n, W, H, schedule):
     prims["matid"] = np.arange(n) % 4
     cb = soup_cb(n)
     ob = orc.build(prims)
-    ctx = gpu_ctx_factory()
-    ctx.set_trace_schedule(schedule)
+    ctx = _ctx_with_schedule(gpu_ctx_factory, monkeypatch, schedule)
     ctx.upload_primitives(prims); ctx.set_constants(cb); ctx.build(); ctx.resize(W, H)
     kd = [list(cb["mats"][0][m]["kd"][:3]) for m in range(16)]
     alb = ptamd.albedo_table(kd)
@@ -357,7 +363,7 @@ def test_material_ids_outside_the_table(gpu_ctx_factory):
     words[2::5, ::3] = -5
     ctx.upload_gbuffer(*gb)
     seeds = ptamd.frame_seeds(2, 0, 3)
-    for schedule in SCHEDULES:
+    for schedule in (ptamd.PT_SCHEDULE_PERSISTENT, ptamd.PT_SCHEDULE_WAVEFRONT):
         ctx.set_trace_schedule(schedule)
         ctx.reset_accumulation()
         ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LITERAL)
