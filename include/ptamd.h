@@ -88,7 +88,8 @@ int pt_set_constants(pt_context *ctx, const pt_CB_Radix *cb);
                                         out-of-range leaf; trees higher than 64 levels are refused
                                         (PT_ERR_UNSUPPORTED).  Different tree, same nearest hits: images differ from
                                         the reference's only where two triangles are hit at equal distance.
-                                        Persistent schedule; pt_set_stack_size 0 or 32 */
+                                        Persistent schedule; pt_set_stack_size 0 or 32.  pt_build synchronises the
+                                        stream with this flag (it reads the height of the finished tree back) */
 #define PT_BUILD_TREE_ONLY      8u   /* the tree and the sorted order only: the per-leaf triangle records of the
                                         trace kernels are not written (the refit then gathers the 32-byte boxes
                                         instead of the 80-byte primitives); pt_primary_hits, pt_intersect and

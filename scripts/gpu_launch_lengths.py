@@ -1,5 +1,5 @@
 """scene04 1162x1008: rays per second against frames per launch (1, 2, 4, 8, 32, 128), for the kernel the PTAMD_*
-knobs of the environment select.  usage: [PTAMD_DUAL=0] python scripts/gpu_launch_lengths.py"""
+knobs of the environment select (WAVEFRONT=1: the wavefront schedule).  usage: [PTAMD_DUAL=0] python scripts/gpu_launch_lengths.py"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +10,8 @@ ctx = ptamd.Context(0)
 ctx.upload_primitives(g["prims"].view(ptamd.PRIM_RENDER)); ctx.set_constants(g["cb"].view(ptamd.CB_RADIX))
 ctx.build(); ctx.resize(1162, 1008)
 ctx.primary_hits(ptamd.default_camera(), ptamd.albedo_table(g["mat_table"][:, 0:3], True))
+if os.environ.get("WAVEFRONT"):
+    ctx.set_trace_schedule(ptamd.PT_SCHEDULE_WAVEFRONT)
 for frames in (1, 2, 4, 8, 32, 128):
     launches = max(4, 256 // frames)
     seeds = [ptamd.frame_seeds(1, k * frames, frames) for k in range(launches)]
@@ -19,5 +21,5 @@ for frames in (1, 2, 4, 8, 32, 128):
         ctx.trace_frames(k * frames, seeds[k], ptamd.PT_ACCUM_LINEAR)
     ctx.synchronize()
     dt = time.perf_counter() - t0
-    print(f"dual={os.environ.get('PTAMD_DUAL', '1')} frames per launch {frames}: {ctx.counters()['rays'] / dt / 1e9:.2f} Grays/s ({dt / launches * 1e3:.2f} ms per launch)", flush=True)
+    print(f"wavefront={os.environ.get('WAVEFRONT', '0')} dual={os.environ.get('PTAMD_DUAL', '1')} frames per launch {frames}: {ctx.counters()['rays'] / dt / 1e9:.2f} Grays/s ({dt / launches * 1e3:.2f} ms per launch)", flush=True)
 ctx.close()
