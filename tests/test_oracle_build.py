@@ -178,3 +178,43 @@ def test_morton_flat_axis_is_cell_zero():
     small["max"][0] = (1, 0.5, 1)
     code = orc.lib().orc_morton(small.ctypes.data_as(C.c_void_p), big.ctypes.data_as(C.c_void_p))
     assert code == 0b101_000_101_000_101              # 21 on x and z, 0 on y
+
+
+def _split_tree(keys, n):
+    """Binary radix tree of n sorted distinct keys by recursive splitting at the highest differing bit (the
+    definition; Karras' searches are a way to find the same splits in parallel): node = first key of the range for a
+    right child, last key for a left child, root 0; leaves n + key."""
+    left, right = {}, {}
+
+    def build(lo, hi, node):
+        if lo == hi:
+            return n + lo
+        top = (keys[lo] ^ keys[hi]).bit_length() - 1                     # highest bit in which the range differs
+        split = lo
+        while ((keys[split + 1] >> top) & 1) == ((keys[lo] >> top) & 1):  # last key that shares the first key's bit
+            split += 1
+        left[node] = build(lo, split, split)
+        right[node] = build(split + 1, hi, split + 1)
+        return node
+    build(0, n - 1, 0)
+    return left, right
+
+
+@pytest.mark.parametrize("n,distinct", [(2, 2), (3, 1), (17, 5), (64, 64), (500, 37), (2000, 2000), (2000, 1)])
+def test_radix_tree_over_codes_equals_recursive_splitting(n, distinct):
+    """NON-PARITY option PT_BUILD_TOPOLOGY_MORTON: the oracle's search-based tree over sorted codes (equal codes told
+    apart by position) against the tree's definition, with codes that use all 63 bits and with heavy ties."""
+    import ctypes as C
+    rng = np.random.default_rng(n * 1000 + distinct)
+    pool = rng.integers(0, 2 ** 63 - 1, size=distinct, dtype=np.uint64)
+    codes = np.sort(rng.choice(pool, size=n))
+    tree = np.zeros(2 * n + 1, dtype=orc.TREENODE)
+    orc.lib().orc_radix_tree_codes(C.c_int(n), codes.ctypes.data_as(C.c_void_p), tree.ctypes.data_as(C.c_void_p))
+    keys = [(int(c) << 32) | i for i, c in enumerate(codes)]             # the (code, position) keys the searches compare
+    left, right = _split_tree(keys, n)
+    assert sorted(left) == list(range(n - 1))
+    for i in range(n - 1):
+        assert tree["left"][i] == left[i] and tree["right"][i] == right[i], i
+        for c in (left[i], right[i]):
+            assert tree["parent"][c] == i
+    assert not tree[n - 1].tobytes().strip(b"\0") and not tree[2 * n].tobytes().strip(b"\0")
