@@ -250,6 +250,16 @@ int pt_set_stack_size(pt_context *ctx, int entries);
 #define PT_TRAVERSAL_NEAR_FIRST 1
 int pt_set_traversal_order(pt_context *ctx, int order);
 
+/* No counterpart in the reference.  The reference's run loop issues one Dispatch per frame; a one-frame launch ends in a
+ * long tail (every lane's last path runs in a wave that empties).  By default short whole-image trace calls (at most 8
+ * frames, tree in LDS, persistent schedule) are therefore OVERLAPPED: their work runs on two library-owned streams used
+ * in turn, so that the next call's paths fill the compute units the previous call's tail leaves idle; the accumulates
+ * keep the order of the calls, and the context's stream waits for each call as soon as it is enqueued, so downloads,
+ * other entry points and the caller's own reads of the images on that stream see finished frames exactly as before.
+ * Overlap is off while a stream of the caller's is set (pt_set_stream with a non-null stream: the library cannot see
+ * the caller's own kernels on it) and with enable = 0 (callers that capture the context's work in a HIP graph). */
+int pt_set_trace_overlap(pt_context *ctx, int enable);
+
 /* longest path, in rays after the G-buffer hit.  The reference ends a path when its counter `itr`
  * (1 at the first bounce, +1 per hit) reaches MAX_ITR * 3 = 15, i.e. after 14 intersect() calls
  * (ray_tracing.hlsl:245-247, 372-387).  0 (default) or 14 keeps that; 1..13 end paths earlier

@@ -2,6 +2,8 @@
 // Host-side only; the kernels live in build_kernels.hip / trace_kernels.hip.
 #include "pt_internal.hpp"
 
+#include <utility>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -81,6 +83,10 @@ static void free_images(pt_context *ctx)
     dev_free(ctx->d_diffuse); dev_free(ctx->d_normal); dev_free(ctx->d_world);
     dev_free(ctx->d_output); dev_free(ctx->d_display); dev_free(ctx->d_linear);
     dev_free(ctx->d_samples); ctx->samples_frames = 0;
+    for (auto &sl : ctx->pipe) {        // sized by the image too
+        if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+        dev_free(sl.d_samples); sl.samples_frames = 0;
+    }
     dev_free(ctx->d_wf_queue[0]); dev_free(ctx->d_wf_queue[1]); dev_free(ctx->d_wf_hits); ctx->wf_paths = 0;
     dev_free(ctx->d_cost); dev_free(ctx->d_pixel_work); dev_free(ctx->d_okeys[0]); dev_free(ctx->d_okeys[1]);
     dev_free(ctx->d_ovals[0]); dev_free(ctx->d_ovals[1]); dev_free(ctx->d_ohist); dev_free(ctx->d_ototal);
@@ -89,10 +95,25 @@ static void free_images(pt_context *ctx)
     ctx->have_gbuffer = false;
 }
 
+// Every entry point that enqueues on the context's stream comes through here (overlapped trace calls excepted):
+// the next overlapped call then makes its internal stream wait for that work first.
 static int set_device(pt_context *ctx)
 {
     PT_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->main_dirty = true;
     return PT_OK;
+}
+
+static void free_pipe(pt_context *ctx)
+{
+    for (auto &sl : ctx->pipe) {
+        if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        dev_free(sl.d_samples); dev_free(sl.d_work); dev_free(sl.d_seeds);
+        sl = pt_context::PipeSlot();
+    }
+    if (ctx->pipe_fork) (void)hipEventDestroy(ctx->pipe_fork);
+    ctx->pipe_fork = nullptr;
 }
 
 extern "C" {
@@ -164,6 +185,7 @@ void pt_destroy(pt_context *ctx)
         if (ctx->h_seeds[k]) (void)hipHostFree(ctx->h_seeds[k]);
         if (ctx->seed_ev[k]) (void)hipEventDestroy(ctx->seed_ev[k]);
     }
+    free_pipe(ctx);
     free_build(ctx);
     free_images(ctx);
     if (ctx->prims_owned) { void *p = const_cast<pt_PrimitiveRender *>(ctx->d_prims); if (p) (void)hipFree(p); }
@@ -193,6 +215,7 @@ int pt_set_stream(pt_context *ctx, void *hip_stream)
     for (int k = 0; k < PT_SEED_SLOTS; k++) ctx->seed_ev_used[k] = false;
     drop_trace_events(ctx);          // an event pair must not span two streams
     ctx->stream = next;
+    ctx->user_stream = next != nullptr;
     return PT_OK;
 }
 
@@ -556,18 +579,59 @@ static int trace_frames(pt_context *ctx, const char *who, uint32_t first_frame, 
     if (int rc = check_trace_ready(ctx, who)) return rc;
     if (!seeds || count < 1) PT_FAIL(ctx, PT_ERR_INVALID, std::string(who) + ": need count >= 1 seeds");
     if (mode != PT_ACCUM_LITERAL && mode != PT_ACCUM_LINEAR) PT_FAIL(ctx, PT_ERR_INVALID, std::string(who) + ": bad mode");
-    if (int rc = set_device(ctx)) return rc;
-    if (ctx->seeds_cap < count) {
-        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        dev_free(ctx->d_seeds);
+    // Short whole-image calls on a tree in LDS are overlapped (see PipeSlot): at most 8 frames, persistent schedule
+    const bool overlapped = ctx->overlap && !ctx->user_stream && !region && count <= 8 && ctx->W * (size_t)ctx->H * count <= ((size_t)1 << 26) &&
+                            ctx->schedule == PT_SCHEDULE_PERSISTENT && ptk_tree_in_lds(ctx);
+    if (!overlapped) { if (int rc = set_device(ctx)) return rc; }
+    else PT_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->h_seeds_cap < count) {
+        // (the staging buffers are shared by the context's stream and the internal ones)
+        PT_HIP(ctx, hipDeviceSynchronize());
         for (int k = 0; k < PT_SEED_SLOTS; k++) { if (ctx->h_seeds[k]) (void)hipHostFree(ctx->h_seeds[k]); ctx->h_seeds[k] = nullptr; }
-        ctx->seeds_cap = 0;
-        if (int rc = dev_alloc(ctx, &ctx->d_seeds, (size_t)count)) return rc;
+        ctx->h_seeds_cap = 0;
         for (int k = 0; k < PT_SEED_SLOTS; k++) {
             PT_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_seeds[k]), (size_t)count * sizeof(uint32_t), hipHostMallocDefault));
             if (!ctx->seed_ev[k]) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->seed_ev[k], hipEventDisableTiming));
             ctx->seed_ev_used[k] = false;
         }
+        ctx->h_seeds_cap = count;
+    }
+    // an overlapped call works with its slot's stream and buffers in the context's place
+    struct Swap {
+        pt_context *c; pt_context::PipeSlot *sl;
+        void flip() {
+            std::swap(c->stream, sl->stream); std::swap(c->d_samples, sl->d_samples); std::swap(c->samples_frames, sl->samples_frames);
+            std::swap(c->d_work, sl->d_work); std::swap(c->d_seeds, sl->d_seeds); std::swap(c->seeds_cap, sl->seeds_cap);
+        }
+        Swap(pt_context *c_, pt_context::PipeSlot *s_) : c(c_), sl(s_) { if (sl) flip(); }
+        ~Swap() { if (sl) { flip(); c->pipe_active = -1; } }
+    };
+    pt_context::PipeSlot *sl = nullptr;
+    if (overlapped) {
+        const int i = ctx->pipe_next;
+        sl = &ctx->pipe[i];
+        if (!sl->stream) {
+            PT_HIP(ctx, hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking));
+            PT_HIP(ctx, hipEventCreateWithFlags(&sl->done, hipEventDisableTiming));
+            if (int rc = dev_alloc(ctx, &sl->d_work, 64)) return rc;
+            if (!ctx->pipe_fork) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_fork, hipEventDisableTiming));
+        }
+        if (ctx->main_dirty) {
+            // whatever the context's stream holds (a build, constants, the G-buffer, a reset of the images) comes first,
+            // for both slots
+            PT_HIP(ctx, hipEventRecord(ctx->pipe_fork, ctx->stream));
+            for (auto &any : ctx->pipe) if (any.stream) PT_HIP(ctx, hipStreamWaitEvent(any.stream, ctx->pipe_fork, 0));
+            ctx->main_dirty = false;
+        }
+        ctx->pipe_next = i ^ 1;
+        ctx->pipe_active = i;
+    }
+    Swap swap(ctx, sl);
+    if (ctx->seeds_cap < count) {
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        dev_free(ctx->d_seeds);
+        ctx->seeds_cap = 0;
+        if (int rc = dev_alloc(ctx, &ctx->d_seeds, (size_t)count)) return rc;
         ctx->seeds_cap = count;
     }
     // pinned staging slots in rotation: the call does not wait for the previous launch, only for the
@@ -580,6 +644,13 @@ static int trace_frames(pt_context *ctx, const char *who, uint32_t first_frame, 
     PT_HIP(ctx, hipEventRecord(ctx->seed_ev[slot], ctx->stream));
     ctx->seed_ev_used[slot] = true;
     if (int rc = ptk_trace_frames(ctx, first_frame, count, mode, region)) return rc;
+    if (sl) {
+        // ctx->stream is the slot's stream here, sl->stream the context's own: the latter waits for this call at once, so
+        // whatever is enqueued on it later (downloads, the caller's own reads of the images) sees the finished frame
+        PT_HIP(ctx, hipEventRecord(sl->done, ctx->stream));
+        sl->used = true;
+        PT_HIP(ctx, hipStreamWaitEvent(sl->stream, sl->done, 0));
+    }
     ctx->frame_count = first_frame + count;
     return PT_OK;
 }
@@ -672,6 +743,14 @@ int pt_set_max_segments(pt_context *ctx, int segments)
     if (!ctx) return PT_ERR_INVALID;
     if (segments < 0 || segments > 14) PT_FAIL(ctx, PT_ERR_INVALID, "pt_set_max_segments: 0 (reference: 14) or 1..14");
     ctx->itr_limit = segments == 0 ? 15 : segments + 1;
+    return PT_OK;
+}
+
+int pt_set_trace_overlap(pt_context *ctx, int enable)
+{
+    if (!ctx) return PT_ERR_INVALID;
+    if (int rc = set_device(ctx)) return rc;
+    ctx->overlap = enable ? 1 : 0;
     return PT_OK;
 }
 

@@ -191,6 +191,30 @@ struct pt_context {
     int seed_slot = 0;
     uint32_t seeds_cap = 0;
 
+    // Overlap of short consecutive trace calls (one frame per call is the reference's own run loop): such a call's seeds
+    // copy, seed, trace and accumulate kernels run on one of two internal streams, used in turn, with the buffers of that
+    // slot, so that the next call's paths fill the CUs that the previous call's last paths leave idle.  Accumulates are
+    // chained through the slots' `done` events (the image recurrence), and the context's own stream waits for every
+    // slot's `done` as soon as it is recorded, so everything else stays ordered with the context's stream as before.
+    struct PipeSlot {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        bool used = false;            // `done` has been recorded at least once
+        float4 *d_samples = nullptr;
+        uint32_t samples_frames = 0;
+        unsigned *d_work = nullptr;
+        uint32_t *d_seeds = nullptr;
+        uint32_t seeds_cap = 0;
+    };
+    PipeSlot pipe[2];
+    hipEvent_t pipe_fork = nullptr;
+    int pipe_next = 0;                // slot of the next overlapped call
+    int pipe_active = -1;             // slot whose buffers are swapped into the context while a call is enqueued
+    bool main_dirty = true;           // work has been enqueued on the context's stream since the last fork
+    bool user_stream = false;         // pt_set_stream gave a stream of the caller's: no overlap (its own kernels are not seen here)
+    int overlap = 1;                  // pt_set_trace_overlap
+    uint32_t h_seeds_cap = 0;         // seeds the pinned staging buffers hold
+
     // options / counters
     int stack_entries = 0;            // 0 = automatic
     int schedule = 0;                 // PT_SCHEDULE_*
@@ -220,5 +244,6 @@ int ptk_export_sorted(pt_context *ctx, pt_PrimitiveRayCS *d_out);
 int ptk_export_tree(pt_context *ctx);
 int ptk_primary(pt_context *ctx, const pt_camera *cam, const uint8_t *d_albedo);
 int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int mode, const int *region);
+bool ptk_tree_in_lds(const pt_context *ctx);
 int ptk_resolve(pt_context *ctx);
 int ptk_intersect(pt_context *ctx, const float *d_rays8, int n_rays, pt_hit *d_out);

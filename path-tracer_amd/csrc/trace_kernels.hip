@@ -1906,6 +1906,13 @@ static uint32_t frames_per_launch(const pt_context *ctx, uint32_t count, bool wa
     return (uint32_t)(count < cap ? count : cap);
 }
 
+bool ptk_tree_in_lds(const pt_context *ctx)
+{
+    int levels = 0;
+    size_t bytes = 0;
+    return !(ctx->build_flags & PT_BUILD_TOPOLOGY_MORTON) && !ctx->knobs.no_lds_tree && lds_resident_threads(ctx, &levels, &bytes) >= 256;
+}
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel variant and context (again only
 // when a later launch needs more)
 template <typename F>
@@ -2088,7 +2095,8 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             // With few items per lane the launch ends ragged unless the expensive pixels go first; with
             // many, image order (neighbouring pixels, similar paths in a wave) is the better order.
             const unsigned long long items = (unsigned long long)n_slots * ((cnt + chunk - 1) / chunk);
-            const bool ordered = !region && !kn.no_order && items < 32ull * lanes;
+            // (an overlapped call keeps image order: the cost keys and their sort belong to the context's stream)
+            const bool ordered = !region && !kn.no_order && items < 32ull * lanes && ctx->pipe_active < 0;
             if (!ordered && !region) ctx->order_valid = false;
             const uint32_t *order = region ? ctx->d_okeys[1] : (ctx->order_valid ? ctx->d_ovals[0] : (const uint32_t *)nullptr);
             PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
@@ -2147,6 +2155,11 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             }
         }
         const dim3 agrid((unsigned)((npix + 255) / 256));
+        if (ctx->pipe_active >= 0) {
+            // the images are a recurrence over the calls: this call's accumulate follows the other slot's
+            pt_context::PipeSlot &other = ctx->pipe[ctx->pipe_active ^ 1];
+            if (other.used) PT_HIP(ctx, hipStreamWaitEvent(ctx->stream, other.done, 0));
+        }
         if (lin) hipLaunchKernelGGL(k_accumulate<true>, agrid, dim3(256), 0, ctx->stream, ctx->d_samples, npix, first, cnt,
                                     ctx->d_output, ctx->d_display, ctx->d_linear, ctx->W, reg);
         else     hipLaunchKernelGGL(k_accumulate<false>, agrid, dim3(256), 0, ctx->stream, ctx->d_samples, npix, first, cnt,

@@ -50,7 +50,7 @@ EXPORTS = (
     "pt_linear_sum_device_ptr", "pt_resolve",
     "pt_comm_unique_id", "pt_comm_init_rank", "pt_comm_destroy", "pt_reduce_linear_sum",
     "pt_download_output", "pt_download_display", "pt_output_device_ptr",
-    "pt_set_stack_size", "pt_set_max_segments", "pt_set_traversal_order", "pt_set_trace_schedule", "pt_set_trace_timing", "pt_get_trace_times", "pt_set_detailed_counters", "pt_get_counters", "pt_reset_counters", "pt_intersect",
+    "pt_set_stack_size", "pt_set_max_segments", "pt_set_traversal_order", "pt_set_trace_overlap", "pt_set_trace_schedule", "pt_set_trace_timing", "pt_get_trace_times", "pt_set_detailed_counters", "pt_get_counters", "pt_reset_counters", "pt_intersect",
 )
 
 
@@ -323,6 +323,9 @@ class Context:
 
     def set_traversal_order(self, order):
         self._ck(self.L.pt_set_traversal_order(self.h, C.c_int(order)))
+
+    def set_trace_overlap(self, enable):
+        self._ck(self.L.pt_set_trace_overlap(self.h, C.c_int(1 if enable else 0)))
 
     def set_trace_schedule(self, schedule):
         self._ck(self.L.pt_set_trace_schedule(self.h, C.c_int(schedule)))

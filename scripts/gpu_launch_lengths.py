@@ -14,8 +14,8 @@ if os.environ.get("NEAR"):
     ctx.set_traversal_order(ptamd.PT_TRAVERSAL_NEAR_FIRST)
 if os.environ.get("WAVEFRONT"):
     ctx.set_trace_schedule(ptamd.PT_SCHEDULE_WAVEFRONT)
-for frames in (1, 2, 4, 8, 32, 128):
-    launches = max(4, 256 // frames)
+for frames in [int(a) for a in sys.argv[1:]] or (1, 2, 4, 8, 32, 128):
+    launches = max(3, 256 // frames)
     seeds = [ptamd.frame_seeds(1, k * frames, frames) for k in range(launches)]
     ctx.trace_frames(0, seeds[0], ptamd.PT_ACCUM_LINEAR); ctx.synchronize(); ctx.reset_counters()
     t0 = time.perf_counter()

@@ -568,3 +568,44 @@ def test_trace_timing_reports_one_duration_per_launch(gpu_ctx_factory, golden):
     ctx.set_trace_timing(False)
     ctx.trace_frames(12, ptamd.frame_seeds(1, 12, 4), ptamd.PT_ACCUM_LINEAR)
     assert len(ctx.trace_times()) == 0
+
+
+def test_overlapped_short_calls_equal_serial_ones(gpu_ctx_factory, golden):
+    """Short trace calls run on two internal streams in turn (pt_set_trace_overlap, the default); the images must be the
+    ones of the same calls issued with overlap off, whatever is mixed in between: single frames, a 4-frame call, a
+    long call on the context's stream, a reset of the images, region dispatches, counters and downloads."""
+    W, H = 192, 144
+    g = golden["scene04"]
+    seeds = ptamd.frame_seeds(1, 0, 64)
+    results = []
+    for overlap in (True, False):
+        ctx = gpu_ctx_factory()
+        ctx.set_trace_overlap(overlap)
+        _setup(ctx, g, W, H)
+        snaps = []
+        for f in range(5):
+            ctx.trace(f, seeds[f])                                  # five overlapped calls in a row
+        snaps.append(ctx.output().copy())
+        ctx.trace_frames(5, seeds[5:9], ptamd.PT_ACCUM_LITERAL)     # four frames: still a short call
+        ctx.trace_frames(9, seeds[9:41], ptamd.PT_ACCUM_LITERAL)    # 32 frames: on the context's stream
+        ctx.trace(41, seeds[41])
+        snaps.append(ctx.output().copy())
+        ctx.trace_region(42, seeds[42], 0, 0, W // 2, H - 1)        # tiles of one frame (never overlapped)
+        ctx.trace_region(42, seeds[42], W // 2 + 1, 0, W - 1, H - 1)
+        ctx.trace(43, seeds[43])
+        snaps.append((ctx.output().copy(), ctx.display().copy(), ctx.counters()))
+        ctx.reset_accumulation()                                    # a reset between overlapped calls
+        ctx.trace(0, seeds[0]); ctx.trace(1, seeds[1])
+        snaps.append(ctx.output().copy())
+        results.append(snaps)
+    a, b = results
+    assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(_bits(a[1]), _bits(b[1]))
+    assert np.array_equal(_bits(a[2][0]), _bits(b[2][0])) and np.array_equal(a[2][1], b[2][1]) and a[2][2] == b[2][2]
+    assert np.array_equal(_bits(a[3]), _bits(b[3]))
+    # and the two-frame restart equals the oracle
+    sc = orc.OracleScene(g["prims"], g["tree"], g["cb"])
+    gb = orc.primary(sc, orc.default_camera(), W, H, ptamd.albedo_table(g["mat_table"][:, 0:3], True))
+    old = np.zeros((H, W, 4), np.float32)
+    for f in range(2):
+        old = orc.trace_frame(sc, gb, f, seeds[f], old)[0]
+    assert np.array_equal(_bits(a[3]), _bits(old))
