@@ -1,6 +1,6 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun -- 'bash scripts/gpu_collect_profiles.sh'): every measurement record kept under profiles/
-# for this round, written to gpurun_out/profiles_r02/ (copy from there into profiles/ and commit).
+# Runs on the GPU box (gpurun -- 'bash scripts/gpu_collect_profiles.sh'): every r02_* measurement record kept under
+# profiles/, written to gpurun_out/profiles_r02/ (copy from there into profiles/ and commit).
 #   r02_bench_default.json            the JSON line of `python bench.py` (run under the profiler: next file)
 #   r02_bench_default_kernel_stats.csv   rocprofv3 --kernel-trace --stats of that same run
 #   r02_trace_pmc.json / r02_build_pmc.json / r02_soup10m_pmc.json   hardware counters, one rocprofv3 --pmc run per group
