@@ -301,6 +301,8 @@ int pt_reset_counters(pt_context *ctx);
  * statistics of the instrumented kernel on stderr at pt_get_counters), PTAMD_PAIR_MAX_MIB (trees that do not
  * fit in LDS are traversed through an array of 128-byte lines holding the records of a node's two children, made at
  * the first trace after a build, as long as that array stays below this size: 65536; 0 = always the plain records),
+ * PTAMD_PAIR_MIN_MIB (... and only when the plain records take at least this much, 24: smaller trees come from the
+ * caches and are read as plain records, their upper levels from LDS unless PTAMD_NO_TOP_LEVELS=1),
  * PTAMD_DUAL=0 (trees in LDS: the single-path persistent kernel instead of the one with two paths per lane, which
  * launches with at least PTAMD_DUAL_MIN_CHUNK = 4 frames per work item use),
  * PTAMD_DUAL_REFILL_T / PTAMD_SHADE_T / PTAMD_SWAP_T / PTAMD_DUAL_LEAF_T (wave-vote thresholds of the latter: 4 / 48 / 4 / 8),

@@ -33,7 +33,9 @@ static void read_knobs(Knobs &k)
     k.chunk = env_int("PTAMD_CHUNK", 0);
     k.print_sched = env_int("PTAMD_PRINT_SCHED", 0);
     k.pair_max_mib = env_int("PTAMD_PAIR_MAX_MIB", k.pair_max_mib);
+    k.pair_min_mib = env_int("PTAMD_PAIR_MIN_MIB", k.pair_min_mib);
     k.gen_lds_entries = env_int("PTAMD_GEN_LDS_ENTRIES", 0);
+    k.no_top_levels = env_int("PTAMD_NO_TOP_LEVELS", 0);
     k.dual = env_int("PTAMD_DUAL", k.dual);
     k.dual_min_chunk = env_int("PTAMD_DUAL_MIN_CHUNK", k.dual_min_chunk);
     k.dual_refill_t = env_int("PTAMD_DUAL_REFILL_T", k.dual_refill_t);

@@ -344,7 +344,11 @@ constexpr int MAX_ITR = 5;   // ray_tracing.hlsl:245-247
 // Per lane the order of node visits, tests and random draws is exactly that of
 // the sequential loop, so results do not change.
 // ---------------------------------------------------------------------------
-struct Tuning { int refill_t, leaf_t; int itr_limit; int swap_t, shade_t; };    // itr_limit: a path ends when itr reaches it (reference: MAX_ITR * 3)
+struct Tuning { int refill_t, leaf_t; int itr_limit; int swap_t, shade_t; };
+// The upper levels of a tree that does not fit in LDS as a whole (index-keyed trees: the node at level k, block b has
+// the compact index off[k] + b): levels k0 .. top are read from LDS, the deeper ones from global memory.
+// k0 > top: nothing in LDS.
+struct TopLevels { int k0, nodes; int off[33]; };    // itr_limit: a path ends when itr reaches it (reference: MAX_ITR * 3)
 
 // ---------------------------------------------------------------------------
 // Path seeds of one launch: seed(pixel, frame) = rand_init(pixel id, g_random[0] of the frame)
@@ -420,20 +424,35 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                                                     float4 *__restrict__ samples, DevCounters *__restrict__ counters,
                                                     unsigned *__restrict__ work_counter,
                                                     const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
-                                                    uint32_t chunk, Tuning tune)
+                                                    uint32_t chunk, Tuning tune, TopLevels top)
 {
-    // LDS: node records (3 float4 each; LDSN only), the 16 materials (3 float4 each), their quotient
-    // records (1 float4 each), then the per-lane stacks
+    // LDS: node records (3 float4 each; LDSN: all of them, else the levels top.k0 and above of an index-keyed tree), the
+    // 16 materials (3 float4 each), their quotient records (1 float4 each), the level offsets of the top part, then the
+    // per-lane stacks
     extern __shared__ __attribute__((aligned(16))) float4 lds_nodes[];
     const int n = sc.n;
     const int nthreads = blockDim.x;
-    float4 *lds_mats = lds_nodes + (LDSN ? 3 * n : 0);
+    const bool TOP = !LDSN && !GEN;
+    float4 *lds_mats = lds_nodes + (LDSN ? 3 * n : (TOP ? 3 * top.nodes : 0));
     float4 *lds_matq = lds_mats + 3 * MAT_SLOTS;
-    float *stack = reinterpret_cast<float *>(lds_matq + MAT_SLOTS) + threadIdx.x;   // level L at stack[(L-1) * nthreads]
+    int *lds_off = reinterpret_cast<int *>(lds_matq + MAT_SLOTS);
+    float *stack = reinterpret_cast<float *>(lds_matq + MAT_SLOTS + (TOP ? 9 : 0)) + threadIdx.x;   // level L at stack[(L-1) * nthreads]
     if (LDSN) {
         for (int i = threadIdx.x; i < 3 * n; i += nthreads) {
             const int node = i / 3, part = i - 3 * node;
             lds_nodes[i] = reinterpret_cast<const float4 *>(&sc.wide[node])[part];
+        }
+    }
+    if (TOP) {
+        if (threadIdx.x < 33) lds_off[threadIdx.x] = top.off[threadIdx.x];
+        for (int i = threadIdx.x; i < top.nodes; i += nthreads) {
+            // compact index -> (level, block) -> node id: a left child is named by its last key, others by their first
+            int k = levels;
+            while (k > top.k0 && i >= top.off[k - 1]) k--;
+            const long long b = i - top.off[k];
+            const int id = ((b & 1) == 0 && ((b + 1) << k) <= (long long)n) ? (int)(((b + 1) << k) - 1) : (int)(b << k);
+            const float4 *src = reinterpret_cast<const float4 *>(&sc.wide[id]);
+            lds_nodes[3 * i] = src[0]; lds_nodes[3 * i + 1] = src[1]; lds_nodes[3 * i + 2] = src[2];
         }
     }
     if (threadIdx.x < 3 * MAT_SLOTS)        // the device copy of the constants ends with the zero material
@@ -712,9 +731,15 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                 if (cur_k >= 1) {                       // only traversing lanes have cur_k >= K_POP
                     float4 w0, w1, w2;
                     float4 a0 = next0, a1 = next1, a2 = next2, b0 = next0, b1 = next1, b2 = next2;
+                    bool from_top = false;
                     if (LDSN) {
                         const float4 *w = lds_nodes + __umul24((unsigned)cur_id, 3u);      // 24-bit multiply: full rate
                         w0 = w[0]; w1 = w[1]; w2 = w[2];
+                    } else if (TOP && cur_k >= top.k0) {
+                        // an upper level of the tree: its records are in LDS under (level offset + block)
+                        const float4 *w = lds_nodes + __umul24((unsigned)(lds_off[cur_k] + (cur_s >> cur_k)), 3u);
+                        w0 = w[0]; w1 = w[1]; w2 = w[2];
+                        from_top = true;
                     } else if (!PAIR) {
                         const float4 *w = reinterpret_cast<const float4 *>(sc.wide + cur_id);
                         w0 = w[0]; w1 = w[1]; w2 = w[2];
@@ -729,7 +754,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                         b0 = w[3]; b1 = w[4]; b2 = w[5];
                         record_from_children(a0, a1, a2, b0, b1, b2, w0, w1, w2);
                     }
-                    const bool fetched_pair = PAIR && !next_valid;
+                    const bool fetched_pair = PAIR && !next_valid && !from_top;
                     const float lmn[3] = {w0.x, w0.y, w0.z}, lmx[3] = {w0.w, w1.x, w1.y};
                     const float rmn[3] = {w1.z, w1.w, w2.x}, rmx[3] = {w2.y, w2.z, w2.w};
                     float tl, tr;
@@ -1978,8 +2003,33 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
     }
     // child lines take twice the memory of the plain records; measured up to 100 M triangles (12.8 GB of lines) they pay
     // at every size that does not fit in LDS (PTAMD_PAIR_MAX_MIB bounds the array; 0 = plain records)
+    // ... once the plain records (64 n bytes) approach the size of the L2s (8 x 4 MiB): below about 400 k triangles the
+    // records come from the caches anyway and the lines' extra instructions and registers cost 10-30 % (PTAMD_PAIR_MIN_MIB)
     const size_t pair_max_nodes = kn.pair_max_mib > 0 ? ((size_t)kn.pair_max_mib << 20) / 128 : 0;
-    const bool use_pair = !lds_nodes && (size_t)ctx->n <= pair_max_nodes;
+    const bool use_pair = !lds_nodes && (size_t)ctx->n <= pair_max_nodes && (size_t)ctx->n * 64 >= ((size_t)kn.pair_min_mib << 20);
+    // Index-keyed trees that do not fit in LDS as a whole and are read as plain records keep their upper levels in LDS: as
+    // many whole levels, from the root down, as fit beside the stacks: 3-9 % (child ids follow from level and block, so
+    // the LDS copy needs no id table; together with child lines it measured 1-5 % slower).
+    TopLevels top{};
+    top.k0 = 33;
+    if (!lds_nodes && !gen && !use_pair && !kn.no_top_levels) {
+        const size_t fixed = MAT_SLOTS * 64 + 144 + (size_t)levels * 4 * threads;
+        const size_t max_nodes = fixed < 160 * 1024 ? (160 * 1024 - fixed) / 48 : 0;
+        size_t acc = 0;
+        int k = levels;
+        for (; k >= 1; k--) {
+            const long long half = 1ll << (k - 1);
+            const size_t cnt = (long long)ctx->n >= half ? (size_t)((((long long)ctx->n - half) >> k) + 1) : 0;
+            if (acc + cnt > max_nodes) break;
+            top.off[k] = (int)acc;
+            acc += cnt;
+        }
+        for (int j = k; j >= 0; j--) top.off[j] = (int)acc;
+        top.k0 = k + 1;
+        top.nodes = (int)acc;
+        lds_bytes += acc * 48;
+    }
+    if (!lds_nodes && !gen) lds_bytes += 144;          // the level-offset table of that variant (present also when unused)
     if (use_pair && !ctx->pair_valid) {
         // the 128-byte child lines of the global-memory traversal, made at the first trace after a build
         // (a build alone does not pay for them)
@@ -2115,7 +2165,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
                 ctx->d_gstack, n_slots, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, seeds, \
                 ctx->d_samples, ctx->d_counters, ctx->d_work, \
                 order, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, \
-                (uint32_t)chunk, tune); } while (0)
+                (uint32_t)chunk, tune, top); } while (0)
             // slot of the variant in ctx->lds_attr: COUNT, LDSN, NEAR as bits; + 10 with pair lines, + 16 / + 22 for trees with
             // explicit child ids (without / with pair lines); 8, 9: wavefront; 28, 29: the per-ray kernels
             // two paths per lane need items of several frames (the two paths are two frames of one pixel): short launches,

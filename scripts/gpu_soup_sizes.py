@@ -1,7 +1,7 @@
 """Render rate of device-generated soups of several sizes with the options of the largest configuration, with and
 without the 128-byte child lines (PTAMD_PAIR_MAX_MIB=0 disables them).
 usage: gpu_soup_sizes.py n1 n2 ...   (run once per setting of PTAMD_PAIR_MAX_MIB; NEAR=1: nearest child first;
-TOPO=1: PT_BUILD_TOPOLOGY_MORTON)"""
+TOPO=1: PT_BUILD_TOPOLOGY_MORTON; FRAMES: frames per launch, default 2)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,8 +28,9 @@ for n in [int(a) for a in sys.argv[1:]]:
     ctx.primary_hits(cam, ptamd.albedo_table([[0.7, 0.6, 0.5]] * 16))
     ctx.set_trace_timing(True)
     ctx.set_detailed_counters(bool(int(os.environ.get("DETAIL", "0"))))
+    fr = int(os.environ.get("FRAMES", "2"))           # frames per launch
     for s in range(3):
-        ctx.trace_frames(2 * s, ptamd.frame_seeds(1, 2 * s, 2), ptamd.PT_ACCUM_LINEAR)
+        ctx.trace_frames(fr * s, ptamd.frame_seeds(1, fr * s, fr), ptamd.PT_ACCUM_LINEAR)
     ms = ctx.trace_times(); c = ctx.counters()
     print(f"n {n} pair_max_mib {os.environ.get('PTAMD_PAIR_MAX_MIB', 'default')} near {os.environ.get('NEAR', '0')} topo {topo}: build {bt['total']:.2f} ms (topology {bt['topology']:.2f}, refit {bt['refit']:.2f}), "
           f"{ms[1:].mean():.1f} ms per launch, {c['rays'] / 3 / (ms[1:].mean() * 1e-3) / 1e6:.1f} Mrays/s, visits/ray {c['node_visits'] / max(c['rays'], 1):.0f}", flush=True)

@@ -59,6 +59,8 @@ def test_large_scene_option_set_against_the_oracle(gpu_ctx_factory, monkeypatch,
     128-byte child lines the traversal reads (the records of both children of a node in one line) and with the plain
     64-byte records (PTAMD_PAIR_MAX_MIB=0, read when the context is created)."""
     n, W, H = 200_000, 200, 150
+    # child lines are used from 24 MiB of plain records on: forced on (or off) for this small tree
+    monkeypatch.setenv("PTAMD_PAIR_MIN_MIB", "0")
     if not pair_lines:
         monkeypatch.setenv("PTAMD_PAIR_MAX_MIB", "0")
     prims = make_soup(n, seed=4242, dtype=ptamd.PRIM_RENDER)
@@ -306,6 +308,8 @@ def test_morton_keyed_topology_against_the_oracle(gpu_ctx_factory, monkeypatch, 
     codes, told apart by position).  Tree, G-buffer, linear sums and counters equal the oracle's restatement of
     the same option bit for bit; the tree is a different one than the reference's, the nearest hits are the same."""
     n, W, H = 200_000, 200, 150
+    # child lines are used from 24 MiB of plain records on: forced on (or off) for this small tree
+    monkeypatch.setenv("PTAMD_PAIR_MIN_MIB", "0")
     if not pair_lines:
         monkeypatch.setenv("PTAMD_PAIR_MAX_MIB", "0")
     if not full:
