@@ -910,7 +910,8 @@ constexpr int P_START = 0, P_READY = 1, P_DONE = 2, P_NONE = 3;
 
 __device__ __forceinline__ void lane_swap(float &a, float &b) { const float t = a; a = b; b = t; }
 
-template <bool COUNT>
+// LDSN = false: index-keyed trees read as plain records from global memory, their upper levels from LDS (TopLevels)
+template <bool COUNT, bool LDSN>
 __global__ __launch_bounds__(1024) void k_trace_dual(SceneView sc, const TriIsect *__restrict__ tri_sorted, int levels,
                                               unsigned n_slots,
                                               const uint8_t *__restrict__ diffuse_tex,
@@ -920,18 +921,33 @@ __global__ __launch_bounds__(1024) void k_trace_dual(SceneView sc, const TriIsec
                                               float4 *__restrict__ samples, DevCounters *__restrict__ counters,
                                               unsigned *__restrict__ work_counter,
                                               const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
-                                              uint32_t chunk, Tuning tune)
+                                              uint32_t chunk, Tuning tune, TopLevels top)
 {
-    // LDS as in k_trace_persistent<LDSN = true>: node records, materials, material quotients, one float per level and lane
+    // LDS as in k_trace_persistent: node records (all, or the upper levels), materials, material quotients, (the level
+    // offsets of the upper levels,) one float per level and lane
     extern __shared__ __attribute__((aligned(16))) float4 lds_nodes[];
     const int n = sc.n;
     const int nthreads = blockDim.x;
-    float4 *lds_mats = lds_nodes + 3 * n;
+    float4 *lds_mats = lds_nodes + (LDSN ? 3 * n : 3 * top.nodes);
     float4 *lds_matq = lds_mats + 3 * MAT_SLOTS;
-    float *stack = reinterpret_cast<float *>(lds_matq + MAT_SLOTS) + threadIdx.x;   // level L at stack[(L-1) * nthreads]
-    for (int i = threadIdx.x; i < 3 * n; i += nthreads) {
-        const int node = i / 3, part = i - 3 * node;
-        lds_nodes[i] = reinterpret_cast<const float4 *>(&sc.wide[node])[part];
+    int *lds_off = reinterpret_cast<int *>(lds_matq + MAT_SLOTS);
+    float *stack = reinterpret_cast<float *>(lds_matq + MAT_SLOTS + (LDSN ? 0 : 9)) + threadIdx.x;   // level L at stack[(L-1) * nthreads]
+    if (LDSN) {
+        for (int i = threadIdx.x; i < 3 * n; i += nthreads) {
+            const int node = i / 3, part = i - 3 * node;
+            lds_nodes[i] = reinterpret_cast<const float4 *>(&sc.wide[node])[part];
+        }
+    } else {
+        if (threadIdx.x < 33) lds_off[threadIdx.x] = top.off[threadIdx.x];
+        for (int i = threadIdx.x; i < top.nodes; i += nthreads) {
+            // compact index -> (level, block) -> node id, as in k_trace_persistent
+            int k = levels;
+            while (k > top.k0 && i >= top.off[k - 1]) k--;
+            const long long bb = i - top.off[k];
+            const int id = ((bb & 1) == 0 && ((bb + 1) << k) <= (long long)n) ? (int)(((bb + 1) << k) - 1) : (int)(bb << k);
+            const float4 *src = reinterpret_cast<const float4 *>(&sc.wide[id]);
+            lds_nodes[3 * i] = src[0]; lds_nodes[3 * i + 1] = src[1]; lds_nodes[3 * i + 2] = src[2];
+        }
     }
     if (threadIdx.x < 3 * MAT_SLOTS) lds_mats[threadIdx.x] = reinterpret_cast<const float4 *>(sc.cb->mats)[threadIdx.x];
     if (threadIdx.x < MAT_SLOTS) {
@@ -1166,7 +1182,10 @@ __global__ __launch_bounds__(1024) void k_trace_dual(SceneView sc, const TriIsec
                     sched[7] += __popcll(ballot64(cur_k == K_NOITEM));
                 }
                 if (cur_k >= 1) {
-                    const float4 *w = lds_nodes + __umul24((unsigned)cur_id, 3u);
+                    const float4 *w;
+                    if (LDSN) w = lds_nodes + __umul24((unsigned)cur_id, 3u);
+                    else if (cur_k >= top.k0) w = lds_nodes + __umul24((unsigned)(lds_off[cur_k] + (cur_s >> cur_k)), 3u);
+                    else w = reinterpret_cast<const float4 *>(sc.wide + cur_id);
                     const float4 w0 = w[0], w1 = w[1], w2 = w[2];
                     const float lmn[3] = {w0.x, w0.y, w0.z}, lmx[3] = {w0.w, w1.x, w1.y};
                     const float rmn[3] = {w1.z, w1.w, w2.x}, rmx[3] = {w2.y, w2.z, w2.w};
@@ -2170,18 +2189,19 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             // explicit child ids (without / with pair lines); 8, 9: wavefront; 28, 29: the per-ray kernels
             // two paths per lane need items of several frames (the two paths are two frames of one pixel): short launches,
             // whose items are one or two frames, run the single-path kernel
-            if (lds_nodes && !near_first && kn.dual && chunk >= (unsigned long long)kn.dual_min_chunk) {
-                // k_trace_dual: slots 30, 31
+            if ((lds_nodes || (!gen && !use_pair)) && !near_first && kn.dual && chunk >= (unsigned long long)kn.dual_min_chunk) {
+                // k_trace_dual: slots 30, 31 (tree in LDS), 18, 19 (plain records from global memory)
                 Tuning dt = tune;
                 dt.refill_t = kn.dual_refill_t;
                 dt.leaf_t = kn.dual_leaf_t;
-#define PT_LAUNCH_DUAL(SLOT, C) do { \
-                if (int rc_ = ensure_lds_limit(ctx, SLOT, &k_trace_dual<C>, lds_bytes)) return rc_; \
+#define PT_LAUNCH_DUAL(SLOT, C, L) do { \
+                if (int rc_ = ensure_lds_limit(ctx, SLOT, &k_trace_dual<C, L>, lds_bytes)) return rc_; \
                 if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream)); \
-                hipLaunchKernelGGL((k_trace_dual<C>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
+                hipLaunchKernelGGL((k_trace_dual<C, L>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
                     n_slots, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, ctx->d_samples, ctx->d_counters, ctx->d_work, \
-                    order, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, (uint32_t)chunk, dt); } while (0)
-                if (ctx->detailed) PT_LAUNCH_DUAL(31, true); else PT_LAUNCH_DUAL(30, false);
+                    order, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, (uint32_t)chunk, dt, top); } while (0)
+                if (lds_nodes) { if (ctx->detailed) PT_LAUNCH_DUAL(31, true, true); else PT_LAUNCH_DUAL(30, false, true); }
+                else           { if (ctx->detailed) PT_LAUNCH_DUAL(19, true, false); else PT_LAUNCH_DUAL(18, false, false); }
 #undef PT_LAUNCH_DUAL
             } else if (near_first) {
                 if (lds_nodes) { if (ctx->detailed) PT_LAUNCH(7, true, true, true); else PT_LAUNCH(6, false, true, true); }

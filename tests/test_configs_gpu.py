@@ -63,6 +63,9 @@ def test_large_scene_option_set_against_the_oracle(gpu_ctx_factory, monkeypatch,
     monkeypatch.setenv("PTAMD_PAIR_MIN_MIB", "0")
     if not pair_lines:
         monkeypatch.setenv("PTAMD_PAIR_MAX_MIB", "0")
+        # plain records, upper levels in LDS: in the reference's order also with two paths per lane (a kernel that
+        # launches with items of four frames or more use; forced onto this two-frame launch)
+        monkeypatch.setenv("PTAMD_DUAL_MIN_CHUNK", "1")
     prims = make_soup(n, seed=4242, dtype=ptamd.PRIM_RENDER)
     prims["vertices"]["pos"] *= np.float32(100.0)
     prims["matid"] = np.where(np.arange(n) % 16 == 0, 4, np.arange(n) % 4)
