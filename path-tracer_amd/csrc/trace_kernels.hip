@@ -432,7 +432,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
     extern __shared__ __attribute__((aligned(16))) float4 lds_nodes[];
     const int n = sc.n;
     const int nthreads = blockDim.x;
-    const bool TOP = !LDSN && !GEN;
+    const bool TOP = !LDSN && !GEN && !PAIR;       // (with child lines the extra branch cost 18 % at 100 M triangles)
     float4 *lds_mats = lds_nodes + (LDSN ? 3 * n : (TOP ? 3 * top.nodes : 0));
     float4 *lds_matq = lds_mats + 3 * MAT_SLOTS;
     int *lds_off = reinterpret_cast<int *>(lds_matq + MAT_SLOTS);
@@ -2053,7 +2053,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
         top.nodes = (int)acc;
         lds_bytes += acc * 48;
     }
-    if (!lds_nodes && !gen) lds_bytes += 144;          // the level-offset table of that variant (present also when unused)
+    if (!lds_nodes && !gen && !use_pair) lds_bytes += 144;          // the level-offset table of that variant (present also when unused)
     if (use_pair && !ctx->pair_valid) {
         // the 128-byte child lines of the global-memory traversal, made at the first trace after a build
         // (a build alone does not pay for them)
