@@ -609,3 +609,34 @@ def test_overlapped_short_calls_equal_serial_ones(gpu_ctx_factory, golden):
     for f in range(2):
         old = orc.trace_frame(sc, gb, f, seeds[f], old)[0]
     assert np.array_equal(_bits(a[3]), _bits(old))
+
+
+@pytest.mark.parametrize("schedule", [ptamd.PT_SCHEDULE_PERSISTENT, "dual"])
+@pytest.mark.parametrize("n", [2700, 3100, 9000])
+def test_trees_around_the_lds_capacity(gpu_ctx_factory, monkeypatch, n, schedule):
+    """Where the tree lives changes with its size: 2700 triangles still fit in LDS (beside fewer waves than scene04's),
+    3100 and 9000 are read as plain records from global memory with their upper levels in LDS (all levels but the
+    lowest one or three).  Each regime, with one and with two paths per lane, against the oracle: images and counters."""
+    W, H = 96, 64
+    prims = make_soup(n, seed=n)
+    prims["matid"] = np.arange(n) % 4
+    cb = soup_cb(n)
+    ob = orc.build(prims)
+    ctx = _ctx_with_schedule(gpu_ctx_factory, monkeypatch, schedule)
+    ctx.upload_primitives(prims); ctx.set_constants(cb); ctx.build(); ctx.resize(W, H)
+    kd = [list(cb["mats"][0][m]["kd"][:3]) for m in range(16)]
+    alb = ptamd.albedo_table(kd)
+    cam = dict(eye=(0.5, 0.5, 3.0), at=(0.5, 0.5, 0.5))
+    ctx.primary_hits(ptamd.default_camera(**cam), alb)
+    sc = orc.OracleScene(prims, ob["tree"], cb)
+    gb = orc.primary(sc, orc.default_camera(**cam), W, H, alb)
+    seeds = ptamd.frame_seeds(11, 0, 5)
+    ctx.set_detailed_counters(True)
+    ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LINEAR)
+    acc = np.zeros((H, W, 4), np.float32)
+    tot = dict(paths=0, rays=0, node_visits=0, box_tests=0, tri_tests=0)
+    for f in range(5):
+        c = orc.trace_frame_linear(sc, gb, f, seeds[f], acc)
+        tot = {k: tot[k] + c[k] for k in tot}
+    assert np.array_equal(_bits(ctx.linear_sum()), _bits(acc))
+    assert ctx.counters() == tot and tot["tri_tests"] > 0
