@@ -475,3 +475,36 @@ def test_morton_keyed_tree_of_equal_codes(gpu_ctx_factory):
     acc = np.zeros((H, W, 4), np.float32)
     c = orc.trace_frame_linear(sc, gb, 0, seeds[0], acc)
     assert np.array_equal(_bits(ctx.linear_sum()), _bits(acc)) and ctx.counters() == c
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 64, 1025])
+def test_morton_keyed_tiny_trees(gpu_ctx_factory, n):
+    """The smallest trees of PT_BUILD_TOPOLOGY_MORTON (two keys: one internal node; 1025 keys: the root crosses the
+    border of the two chunks of the refit): tree and one traced frame against the oracle."""
+    W, H = 48, 32
+    rng = np.random.default_rng(n)
+    prims = make_soup(n, seed=n, dtype=ptamd.PRIM_RENDER)
+    prims["vertices"]["pos"] = (rng.random((n, 3, 3), dtype=np.float32) * np.float32(60) + np.float32(20))
+    prims["matid"] = np.arange(n) % 4
+    ctx = gpu_ctx_factory()
+    cb, alb = _soup_setup(ctx, prims, W, H, ptamd.PT_BUILD_TOPOLOGY_MORTON | ptamd.PT_BUILD_MORTON_FULL)
+    ob = orc.build_codes_topology(prims.view(orc.PRIM_RENDER), True)
+    _same_tree(ctx.tree(), ob["tree"][:2 * n])
+    ocam = orc.default_camera(**CAM); ocam.zfar = 1000.0
+    sc = orc.OracleScene(prims.view(orc.PRIM_RENDER), ob["tree"], cb, stack_size=120, max_segments=8)
+    gb = orc.primary(sc, ocam, W, H, alb)
+    d, nn, w = ctx.download_gbuffer()
+    assert np.array_equal(d, gb[0]) and np.array_equal(_bits(nn), _bits(gb[1])) and np.array_equal(_bits(w), _bits(gb[2]))
+    ctx.set_detailed_counters(True)
+    seeds = ptamd.frame_seeds(1, 0, 2)
+    ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LINEAR)
+    acc = np.zeros((H, W, 4), np.float32)
+    tot = dict(paths=0, rays=0, node_visits=0, box_tests=0, tri_tests=0)
+    for f in range(2):
+        c = orc.trace_frame_linear(sc, gb, f, seeds[f], acc)
+        tot = {k: tot[k] + c[k] for k in tot}
+    assert np.array_equal(_bits(ctx.linear_sum()), _bits(acc)) and ctx.counters() == tot
+    # one primitive has no internal node: refused
+    ctx.upload_primitives(prims[:1])
+    with pytest.raises(ptamd.PtError):
+        ctx.build(ptamd.PT_BUILD_TOPOLOGY_MORTON)
