@@ -54,7 +54,7 @@ void RayTracer::loadScene(const char *filename)
     // boxes, scene box, Morton codes, sort (and the tree) on the GPU
     if (!ensureContext()) return;
     if (!check(pt_upload_primitives(ctx_, renderer_primitives.data(), primitive_count), "pt_upload_primitives")) return;
-    if (!check(pt_build(ctx_, PT_BUILD_DEFAULT), "pt_build")) return;
+    if (!check(pt_build(ctx_, build_flags), "pt_build")) return;
     has_built_ = true;
     const size_t n = (size_t)primitive_count;
     std::vector<uint64_t> codes(n);
@@ -150,7 +150,9 @@ void RayTracer::resize(int w, int h)
 
 void RayTracer::buildRadixTree()
 {
-    if (ctx_ && primitive_count > 0) has_built_ = check(pt_build(ctx_, PT_BUILD_DEFAULT), "pt_build");
+    flush();                                // queued frames belong to the tree they were queued under
+    if (ctx_ && primitive_count > 0) has_built_ = check(pt_build(ctx_, build_flags), "pt_build");
+    gbuffer_ready_ = false;
 }
 
 void RayTracer::buildBVH() {}

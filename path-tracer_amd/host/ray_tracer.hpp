@@ -69,6 +69,10 @@ public:
     // one launch per frame; a launch of 32 frames takes half the time of 32 launches.  1 = launch in run().
     int frames_per_launch = 32;
     void flush();
+    // flags handed to pt_build by loadScene() and buildRadixTree().  PT_BUILD_DEFAULT builds the
+    // reference's tree (radix_tree_build.hlsl:25-137); PT_BUILD_MORTON_FULL / PT_BUILD_TOPOLOGY_MORTON
+    // are the labelled non-parity options for large scenes.  Set before loadScene().
+    unsigned build_flags = PT_BUILD_DEFAULT;
     // the reference's TILEX / TILEY (ray_tracer.cpp:298-299, compiled as 1): the image is traced in
     // tiles_x * tiles_y dispatches per frame, each over width / tiles_x by height / tiles_y pixels with
     // the offset and inclusive bounds of ray_tracer.cpp:319-322.  The reference draws a new seed per

@@ -137,6 +137,49 @@ def test_raytracer_resize_acc_toggle_and_tiles(golden, monkeypatch):
         L.pth_tracer_free(r)
 
 
+def test_raytracer_class_build_flags(golden, monkeypatch):
+    """`build_flags` reaches pt_build: with the tree over the Morton codes the facade's public tree is the oracle's
+    for that option and the frames are the oracle's over that tree; back to the default, the reference's tree."""
+    monkeypatch.chdir(os.path.join(GOLDEN, "scenes"))
+    L = _tracer_lib()
+    L.pth_tracer_set_build_flags.argtypes = [C.c_void_p, C.c_uint]
+    L.pth_tracer_rebuild.argtypes = [C.c_void_p]
+    L.pth_tracer_members.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    W, H, frames = 96, 80, 2
+    g = golden["scene04"]
+    n = len(g["prims"])
+    r = L.pth_tracer_new(0)
+    try:
+        L.pth_tracer_set_build_flags(r, ptamd.PT_BUILD_TOPOLOGY_MORTON)
+        assert L.pth_tracer_load(r, b"scene04.obj", W, H) == n, L.pth_tracer_error(r)
+        tree = np.zeros(2 * n, dtype=orc.TREENODE)
+        assert L.pth_tracer_members(r, None, None, tree.ctypes.data_as(C.c_void_p)) == 0
+        ob = orc.build_codes_topology(g["prims"])
+        for f in ("left", "right", "parent", "index"):
+            assert np.array_equal(tree[f], ob["tree"][:2 * n][f]), f
+        assert np.array_equal(tree["bound"]["min"], ob["tree"][:2 * n]["bound"]["min"])
+        assert np.array_equal(tree["bound"]["max"], ob["tree"][:2 * n]["bound"]["max"])
+        assert L.pth_tracer_run(r, frames) == frames, L.pth_tracer_error(r)
+        out, disp = _read(L, r, W, H)
+        sc = orc.OracleScene(g["prims"], ob["tree"], g["cb"], stack_size=120)
+        kd = [list(m[0:3]) for m in g["mat_table"]] + [[0, 0, 0]] * (16 - len(g["mat_table"]))
+        gb = orc.primary(sc, orc.default_camera(), W, H, orc.albedo_table(g["cb"], True, kd_override=kd))
+        old = np.zeros((H, W, 4), np.float32)
+        seeds = orc.frame_seeds(1, 0, frames)
+        for f in range(frames):
+            old, outu, _, _ = orc.trace_frame(sc, gb, f, seeds[f], old)
+        assert out.tobytes() == old.tobytes()
+        assert np.array_equal(disp, outu)
+        # the default again: the reference's tree
+        L.pth_tracer_set_build_flags(r, ptamd.PT_BUILD_DEFAULT)
+        assert L.pth_tracer_rebuild(r) == 0, L.pth_tracer_error(r)
+        assert L.pth_tracer_members(r, None, None, tree.ctypes.data_as(C.c_void_p)) == 0
+        assert np.array_equal(tree["left"], g["tree"][:2 * n]["left"])
+        assert np.array_equal(tree["parent"], g["tree"][:2 * n]["parent"])
+    finally:
+        L.pth_tracer_free(r)
+
+
 def test_headless_driver_writes_snapshot(tmp_path):
     exe = os.path.join(ROOT, "path-tracer_amd", "host", "pt_headless")
     out = tmp_path / "snap.bmp"
