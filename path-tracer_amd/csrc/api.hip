@@ -612,12 +612,14 @@ static int trace_frames(pt_context *ctx, const char *who, uint32_t first_frame, 
     if (overlapped) {
         const int i = ctx->pipe_next;
         sl = &ctx->pipe[i];
+        // (each piece on its own: a call that failed half-way leaves a slot the next call completes)
         if (!sl->stream) {
             PT_HIP(ctx, hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking));
-            PT_HIP(ctx, hipEventCreateWithFlags(&sl->done, hipEventDisableTiming));
-            if (int rc = dev_alloc(ctx, &sl->d_work, 64)) return rc;
-            if (!ctx->pipe_fork) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_fork, hipEventDisableTiming));
+            ctx->main_dirty = true;           // a new stream has not waited for anything the context's stream holds
         }
+        if (!sl->done) PT_HIP(ctx, hipEventCreateWithFlags(&sl->done, hipEventDisableTiming));
+        if (!sl->d_work) { if (int rc = dev_alloc(ctx, &sl->d_work, 64)) return rc; }
+        if (!ctx->pipe_fork) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_fork, hipEventDisableTiming));
         if (ctx->main_dirty) {
             // whatever the context's stream holds (a build, constants, the G-buffer, a reset of the images) comes first,
             // for both slots

@@ -370,8 +370,8 @@ __device__ __forceinline__ int node_id(long long b, int k, int n)
 __device__ __forceinline__ void write_wide(WideNode *__restrict__ w, const float *L, const float *R, int left, int right)
 {
     float4 *dst = reinterpret_cast<float4 *>(w);
-    // ordinary stores: a workgroup's node ids are scattered (a left child is named by its last key), and
-    // streaming stores of partial lines made this kernel three times slower
+    // (the few nodes of the upper levels; the lower levels stage their records through LDS.)  Ordinary stores:
+    // streaming stores of partial lines made the refit three times slower
     dst[0] = make_float4(L[0], L[1], L[2], L[3]);
     dst[1] = make_float4(L[4], L[5], R[0], R[1]);
     dst[2] = make_float4(R[2], R[3], R[4], R[5]);
@@ -412,7 +412,11 @@ __global__ __launch_bounds__(PT_REFIT_CHUNK) void k_refit_low(const uint32_t *__
                                                    int n, WideNode *__restrict__ wide, ChunkBox *__restrict__ chunk,
                                                    TriIsect *__restrict__ tri, TriShade *__restrict__ shade)
 {
+    // 48 KB that stage what the chunk writes, so that store instructions write whole lines: with PACK the per-leaf
+    // records first, then (both variants) the boxes of the chunk's node records, 48 bytes per node id of the chunk
+    __shared__ float4 lds[3 * PT_REFIT_CHUNK];
     __shared__ float sb[6][PT_REFIT_CHUNK];          // 24 KB: min.xyz, max.xyz per key slot
+    __shared__ unsigned short meta[PT_REFIT_CHUNK];  // per node id of the chunk: level << 10 | first key slot; 0 = not written here
     const int t = threadIdx.x;
     const long long base = (long long)blockIdx.x * PT_REFIT_CHUNK;
     {   // one key per lane: every gather of the chunk is in flight at once
@@ -420,6 +424,7 @@ __global__ __launch_bounds__(PT_REFIT_CHUNK) void k_refit_low(const uint32_t *__
         long long key = base + j;
         float b[6] = {0, 0, 0, 0, 0, 0};
         if (PACK) {
+            float4 r[6] = {};
             if (key <= n) {
                 const int p = (key < n) ? (int)perm[key] : 0;
                 const float4 *src = reinterpret_cast<const float4 *>(prims16 + (size_t)p * (PRIM_DW / 4));
@@ -436,14 +441,28 @@ __global__ __launch_bounds__(PT_REFIT_CHUNK) void k_refit_low(const uint32_t *__
                         b[k] = (x < yz_min) ? x : yz_min;
                     }
                 }
-                float4 *td = reinterpret_cast<float4 *>(&tri[key]);
-                td[0] = make_float4(A[0], A[1], A[2], __int_as_float(p));
-                td[1] = make_float4(B[0] - A[0], B[1] - A[1], B[2] - A[2], 0.0f);
-                td[2] = make_float4(C[0] - A[0], C[1] - A[1], C[2] - A[2], 0.0f);
-                float4 *sd = reinterpret_cast<float4 *>(&shade[key]);
-                sd[0] = make_float4(v0.w, v1.x, v1.y, v4.z);          // normal 0, material id (bits)
-                sd[1] = make_float4(v2.y, v2.z, v2.w, 0.0f);
-                sd[2] = make_float4(v3.w, v4.x, v4.y, 0.0f);
+                r[0] = make_float4(A[0], A[1], A[2], __int_as_float(p));
+                r[1] = make_float4(B[0] - A[0], B[1] - A[1], B[2] - A[2], 0.0f);
+                r[2] = make_float4(C[0] - A[0], C[1] - A[1], C[2] - A[2], 0.0f);
+                r[3] = make_float4(v0.w, v1.x, v1.y, v4.z);           // normal 0, material id (bits)
+                r[4] = make_float4(v2.y, v2.z, v2.w, 0.0f);
+                r[5] = make_float4(v3.w, v4.x, v4.y, 0.0f);
+            }
+            // The records of a chunk are 48 KB of consecutive bytes per array, 48 bytes per lane: written from the lanes a
+            // store instruction would touch 24 lines with 16 bytes each; through LDS every instruction writes 1 KiB in a row.
+            const long long left_keys = (long long)n + 1 - base;
+            const int quads = 3 * (int)(left_keys < PT_REFIT_CHUNK ? left_keys : PT_REFIT_CHUNK);
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                lds[3 * t] = r[3 * a]; lds[3 * t + 1] = r[3 * a + 1]; lds[3 * t + 2] = r[3 * a + 2];
+                __syncthreads();
+                float4 *dst = a == 0 ? reinterpret_cast<float4 *>(tri + base) : reinterpret_cast<float4 *>(shade + base);
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const int q = t + i * PT_REFIT_CHUNK;
+                    if (q < quads) dst[q] = lds[q];
+                }
+                __syncthreads();
             }
         } else if (key < n) {
             const int p = (int)perm[key];
@@ -453,6 +472,7 @@ __global__ __launch_bounds__(PT_REFIT_CHUNK) void k_refit_low(const uint32_t *__
         }
 #pragma unroll
         for (int c = 0; c < 6; c++) sb[c][j] = b[c];
+        meta[j] = 0;
     }
     __syncthreads();
     for (int k = 1; k <= PT_REFIT_CHUNK_LOG2; k++) {
@@ -467,14 +487,12 @@ __global__ __launch_bounds__(PT_REFIT_CHUNK) void k_refit_low(const uint32_t *__
                 for (int c = 0; c < 6; c++) { L[c] = sb[c][ls]; R[c] = sb[c][rs]; }
 #pragma unroll
                 for (int c = 0; c < 3; c++) { U[c] = fminf(L[c], R[c]); U[3 + c] = fmaxf(L[3 + c], R[3 + c]); }
-                const long long b = s >> k;
-                const int id = node_id(b, k, n);
-                const long long gamma = s + half - 1;
-                const long long e = min(s + (1ll << k) - 1, (long long)n);
-                // a leaf child is named ~key (its position in the sorted order)
-                const int left = (k == 1) ? ~(int)s : (int)gamma;
-                const int right = (gamma + 1 == e) ? ~(int)(gamma + 1) : (int)(gamma + 1);
-                write_wide(&wide[id], L, R, left, right);
+                // the node's id lies in the chunk's key range (node_id: the first or the last key of the node's range)
+                const int slot = (int)(node_id(s >> k, k, n) - base);
+                lds[3 * slot] = make_float4(L[0], L[1], L[2], L[3]);
+                lds[3 * slot + 1] = make_float4(L[4], L[5], R[0], R[1]);
+                lds[3 * slot + 2] = make_float4(R[2], R[3], R[4], R[5]);
+                meta[slot] = (unsigned short)((k << 10) | ls);
 #pragma unroll
                 for (int c = 0; c < 6; c++) sb[c][ls] = U[c];
             }
@@ -482,6 +500,25 @@ __global__ __launch_bounds__(PT_REFIT_CHUNK) void k_refit_low(const uint32_t *__
         __syncthreads();
     }
     if (t < 6) (&chunk[blockIdx.x].mn[0])[t] = sb[t][0];
+    // The chunk's node records are 64 KB of consecutive bytes (one id of the range belongs to a node of a higher level and
+    // is skipped): written record by record as the levels finish, a store instruction touched 64 lines with 16 bytes each.
+    float4 *dst = reinterpret_cast<float4 *>(wide + base);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int q = t + i * PT_REFIT_CHUNK, slot = q >> 2, part = q & 3;
+        const unsigned m = meta[slot];
+        const int k = (int)(m >> 10);
+        if (k != 0) {
+            const long long s = base + (long long)(m & 1023u);
+            const long long gamma = s + (1ll << (k - 1)) - 1;
+            const long long e = min(s + (1ll << k) - 1, (long long)n);
+            // a leaf child is named ~key (its position in the sorted order)
+            const int left = (k == 1) ? ~(int)s : (int)gamma;
+            const int right = (gamma + 1 == e) ? ~(int)(gamma + 1) : (int)(gamma + 1);
+            const float4 box = lds[3 * slot + (part < 3 ? part : 0)];
+            dst[q] = part < 3 ? box : make_float4(__int_as_float(left), __int_as_float(right), 0.0f, 0.0f);
+        }
+    }
 }
 
 // Levels above a unit (a unit = the box of 2^base consecutive keys: a 1024-key chunk, or a
@@ -696,11 +733,15 @@ __global__ __launch_bounds__(PT_REFIT_CHUNK) void k_refit_chunk(const uint32_t *
                                                      WideNode *__restrict__ wide, TriIsect *__restrict__ tri, TriShade *__restrict__ shade)
 {
     __shared__ float lb[6][PT_REFIT_CHUNK];          // leaf boxes
-    __shared__ float nb[6][PT_REFIT_CHUNK];          // node boxes
-    __shared__ int hh[PT_REFIT_CHUNK];               // node heights; 0 = not finished yet
+    // 48 KB used three times: staging of the per-leaf records (PACK), the node boxes and heights of the rounds, staging
+    // of the node records -- so that store instructions write whole lines (see k_refit_low)
+    __shared__ float4 lds[3 * PT_REFIT_CHUNK];
+    float (*nb)[PT_REFIT_CHUNK] = reinterpret_cast<float (*)[PT_REFIT_CHUNK]>(lds);     // node boxes
+    int *hh = reinterpret_cast<int *>(lds) + 6 * PT_REFIT_CHUNK;                         // node heights; 0 = not finished yet
     const int t = threadIdx.x;
     const int base = blockIdx.x * PT_REFIT_CHUNK;
     const int key = base + t;
+    float4 r[6] = {};
     if (key < n) {
         const int p = (int)perm[key];
         float b[6];
@@ -716,14 +757,12 @@ __global__ __launch_bounds__(PT_REFIT_CHUNK) void k_refit_chunk(const uint32_t *
                 b[3 + k] = (x > yz_max) ? x : yz_max;
                 b[k] = (x < yz_min) ? x : yz_min;
             }
-            float4 *td = reinterpret_cast<float4 *>(&tri[key]);
-            td[0] = make_float4(A[0], A[1], A[2], __int_as_float(p));
-            td[1] = make_float4(B[0] - A[0], B[1] - A[1], B[2] - A[2], 0.0f);
-            td[2] = make_float4(C[0] - A[0], C[1] - A[1], C[2] - A[2], 0.0f);
-            float4 *sd = reinterpret_cast<float4 *>(&shade[key]);
-            sd[0] = make_float4(v0.w, v1.x, v1.y, v4.z);
-            sd[1] = make_float4(v2.y, v2.z, v2.w, 0.0f);
-            sd[2] = make_float4(v3.w, v4.x, v4.y, 0.0f);
+            r[0] = make_float4(A[0], A[1], A[2], __int_as_float(p));
+            r[1] = make_float4(B[0] - A[0], B[1] - A[1], B[2] - A[2], 0.0f);
+            r[2] = make_float4(C[0] - A[0], C[1] - A[1], C[2] - A[2], 0.0f);
+            r[3] = make_float4(v0.w, v1.x, v1.y, v4.z);
+            r[4] = make_float4(v2.y, v2.z, v2.w, 0.0f);
+            r[5] = make_float4(v3.w, v4.x, v4.y, 0.0f);
         } else {
             const float4 *src = reinterpret_cast<const float4 *>(&boxes[p]);
             const float4 lo = src[0], hi = src[1];
@@ -731,6 +770,22 @@ __global__ __launch_bounds__(PT_REFIT_CHUNK) void k_refit_chunk(const uint32_t *
         }
 #pragma unroll
         for (int c = 0; c < 6; c++) lb[c][t] = b[c];
+    }
+    if (PACK) {
+        const int left_keys = n - base;
+        const int quads = 3 * (left_keys < PT_REFIT_CHUNK ? left_keys : PT_REFIT_CHUNK);
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            lds[3 * t] = r[3 * a]; lds[3 * t + 1] = r[3 * a + 1]; lds[3 * t + 2] = r[3 * a + 2];
+            __syncthreads();
+            float4 *dst = a == 0 ? reinterpret_cast<float4 *>(tri + base) : reinterpret_cast<float4 *>(shade + base);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const int q = t + i * PT_REFIT_CHUNK;
+                if (q < quads) dst[q] = lds[q];
+            }
+            __syncthreads();
+        }
     }
     int left = 0, right = 0;
     bool todo = false;
@@ -741,6 +796,10 @@ __global__ __launch_bounds__(PT_REFIT_CHUNK) void k_refit_chunk(const uint32_t *
         right = (ln.y & LINK_RIGHT_LEAF) ? ~(gamma + 1) : gamma + 1;
         todo = (ln.y & LINK_IN_CHUNK) != 0;
     }
+    const bool mine = todo;                          // this workgroup writes the node's record
+    // A node the rounds cannot finish (a chunk subtree higher than the supported tree height) keeps HEIGHT_UNFINISHED
+    float KL[6] = {0, 0, 0, 0, 0, 0}, KR[6] = {0, 0, 0, 0, 0, 0};
+    int kh = HEIGHT_UNFINISHED;
     hh[t] = 0;
     __syncthreads();
     // every descendant of a node of this chunk is a leaf or a node of this chunk: slots left - base, ~left - base
@@ -765,14 +824,35 @@ __global__ __launch_bounds__(PT_REFIT_CHUNK) void k_refit_chunk(const uint32_t *
 #pragma unroll
             for (int c = 0; c < 3; c++) { nb[c][t] = fminf(L[c], R[c]); nb[3 + c][t] = fmaxf(L[3 + c], R[3 + c]); }
             hh[t] = h;
-            write_wide_h(&wide[key], L, R, left, right, h);
+#pragma unroll
+            for (int c = 0; c < 6; c++) { KL[c] = L[c]; KR[c] = R[c]; }
+            kh = h;
             todo = false;
         }
         __syncthreads();
     }
-    if (todo) {
-        const float z[6] = {0, 0, 0, 0, 0, 0};
-        write_wide_h(&wide[key], z, z, left, right, HEIGHT_UNFINISHED);
+    // The records of the chunk's nodes, 64 bytes each at consecutive ids: 512 at a time through LDS (80 bytes apart there:
+    // no bank conflicts), skipping the ids of nodes that cross a chunk border (k_refit_cross writes those)
+    float4 *dst = reinterpret_cast<float4 *>(wide + base);
+    for (int half = 0; half < 2; half++) {
+        if ((t >> 9) == half) {
+            const int s = 5 * (t & 511);
+            lds[s] = make_float4(KL[0], KL[1], KL[2], KL[3]);
+            lds[s + 1] = make_float4(KL[4], KL[5], KR[0], KR[1]);
+            lds[s + 2] = make_float4(KR[2], KR[3], KR[4], KR[5]);
+            lds[s + 3] = make_float4(__int_as_float(left), __int_as_float(right), __int_as_float(kh), mine ? 1.0f : 0.0f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int q = t + i * PT_REFIT_CHUNK, rec = q >> 2, part = q & 3;
+            if (lds[5 * rec + 3].w != 0.0f) {
+                float4 v = lds[5 * rec + part];
+                if (part == 3) v.w = 0.0f;
+                dst[half * 2 * PT_REFIT_CHUNK + q] = v;
+            }
+        }
+        __syncthreads();
     }
 }
 
