@@ -54,7 +54,7 @@ BUILD_BYTES_DEFAULT = 376 + 96
 # bytes each stage's kernels request per triangle (what this implementation reads + writes, by design)
 STAGE_BYTES = {
     "tree_only": {"bounds": 80 + 32, "morton": 32 + 4, "sort": (4 + 4 + 8) + (4 + 8 + 4), "refit": 4 + 32 + 64},
-    "default": {"bounds": 80 + 32, "morton": 32 + 4, "sort": (4 + 4 + 8) + (4 + 8 + 4), "refit": 4 + 80 + 64 + 96},
+    "default": {"bounds": 80 + 12, "morton": 12 + 4, "sort": (4 + 4 + 8) + (4 + 8 + 4), "refit": 4 + 80 + 64 + 96},
 }
 PROFILE_TRACE = os.path.join(ROOT, "profiles", "r02_trace_pmc.json")
 PROFILE_BUILD = os.path.join(ROOT, "profiles", "r02_build_pmc.json")

@@ -60,7 +60,10 @@ const char *pt_version(void);
  * every `matid` and fails with PT_ERR_UNSUPPORTED outside 0..15.  Device-side inputs cannot be checked
  * up front (pt_upload_primitives_device, the G-buffer's asint(normal.w) - 1): there an id outside
  * 0..15 reads an all-zero material, as an out-of-range constant-buffer read does in Direct3D 11, and
- * never memory beyond the table; a non-positive G-buffer material word is background. */
+ * never memory beyond the table; a non-positive G-buffer material word is background.
+ * pt_upload_primitives_device keeps the caller's pointer (no copy): the records must stay valid and
+ * unchanged until the next upload or pt_destroy -- pt_primary_hits and the build-product downloads read
+ * them again after pt_build. */
 int pt_upload_primitives(pt_context *ctx, const pt_PrimitiveRender *host_prims, int n);
 int pt_upload_primitives_device(pt_context *ctx, const void *dev_prims, int n);
 /* replaces: the per-frame Map/write of constant_buffers_[0] (CS.cpp:405-439).

@@ -56,6 +56,9 @@ __device__ __forceinline__ float wave_max(float v)
 // ---------------------------------------------------------------------------
 constexpr int PRIM_DW = 20;   // dwords per PrimitiveRender
 
+// MIDS: the default build of the index-keyed tree needs of a box only its centre, for the Morton code (its refit fetches
+// the primitive itself): 12 bytes per triangle are written in the boxes' place, (min + max) / 2 as structs.hpp:90-92 forms it.
+template <bool MIDS>
 __global__ __launch_bounds__(256) void k_bounds(const uint4 *__restrict__ prims16, int n,
                                                 BoxRec *__restrict__ boxes, float *__restrict__ partial)
 {
@@ -80,12 +83,15 @@ __global__ __launch_bounds__(256) void k_bounds(const uint4 *__restrict__ prims1
             mx[k] = (x > yz_max) ? x : yz_max;
             mn[k] = (x < yz_min) ? x : yz_min;
         }
-        BoxRec b;
-        b.mn[0] = mn[0]; b.mn[1] = mn[1]; b.mn[2] = mn[2]; b.pad = 0.0f;
-        b.mx[0] = mx[0]; b.mx[1] = mx[1]; b.mx[2] = mx[2]; b.index = (int32_t)(first + t);
-        float4 *dst = reinterpret_cast<float4 *>(&boxes[first + t]);
-        nt_store4(&dst[0], b.mn[0], b.mn[1], b.mn[2], 0.0f);
-        nt_store4(&dst[1], b.mx[0], b.mx[1], b.mx[2], __int_as_float(b.index));
+        if (MIDS) {
+            float *dst = reinterpret_cast<float *>(boxes) + 3 * (first + t);
+#pragma unroll
+            for (int k = 0; k < 3; k++) dst[k] = (mn[k] + mx[k]) / 2;
+        } else {
+            float4 *dst = reinterpret_cast<float4 *>(&boxes[first + t]);
+            nt_store4(&dst[0], mn[0], mn[1], mn[2], 0.0f);
+            nt_store4(&dst[1], mx[0], mx[1], mx[2], __int_as_float((int32_t)(first + t)));
+        }
     } else {
         const float inf = __uint_as_float(0x7f800000u);
 #pragma unroll
@@ -143,20 +149,26 @@ __device__ __forceinline__ uint64_t spread3(uint64_t v)
     return v;
 }
 
-template <typename K>
+template <typename K, bool MIDS>
 __global__ __launch_bounds__(256) void k_morton(const BoxRec *__restrict__ boxes, int n,
                                                 const unsigned *__restrict__ bbox_enc, float cells,
                                                 K *__restrict__ codes)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float4 *src = reinterpret_cast<const float4 *>(&boxes[i]);
-    float4 lo = src[0], hi = src[1];
+    float midx, midy, midz;
+    if (MIDS) {
+        const float *src = reinterpret_cast<const float *>(boxes) + 3 * (size_t)i;
+        midx = src[0]; midy = src[1]; midz = src[2];
+    } else {
+        const float4 *src = reinterpret_cast<const float4 *>(&boxes[i]);
+        const float4 lo = src[0], hi = src[1];
+        midx = (lo.x + hi.x) / 2;
+        midy = (lo.y + hi.y) / 2;
+        midz = (lo.z + hi.z) / 2;
+    }
     float min_x = dec_f(bbox_enc[0]), min_y = dec_f(bbox_enc[1]), min_z = dec_f(bbox_enc[2]);
     float max_x = dec_f(bbox_enc[3]), max_y = dec_f(bbox_enc[4]), max_z = dec_f(bbox_enc[5]);
-    float midx = (lo.x + hi.x) / 2;
-    float midy = (lo.y + hi.y) / 2;
-    float midz = (lo.z + hi.z) / 2;
     // a flat axis of the scene box gives 0/0 = NaN: cell 0 (what the x86 conversion of the reference
     // leaves in the bits it interleaves)
     const float qa = ((midx - min_x) / (max_x - min_x)) * cells;
@@ -991,6 +1003,8 @@ int ptk_order_pixels(pt_context *ctx, int shift)
 // Stages bounds .. refit over the buffers of `b`.  `ev` (PT_STAGE_COUNT + 1 events) receives the
 // stage boundaries up to the end of the refit, or is null.  Returns which of b.vals holds the
 // permutation in *sorted_buf.
+static bool build_keeps_centres_only(unsigned flags) { return (flags & (PT_BUILD_TREE_ONLY | PT_BUILD_TOPOLOGY_MORTON)) == 0; }
+
 static int run_build(pt_context *ctx, const BuildBufs &b, const uint4 *prims16, int n, unsigned flags,
                      hipEvent_t *ev, int *sorted_buf)
 {
@@ -998,17 +1012,20 @@ static int run_build(pt_context *ctx, const BuildBufs &b, const uint4 *prims16, 
     const int grid_n = (n + 255) / 256;
 
     if (ev) PT_HIP(ctx, hipEventRecord(ev[0], st));
-    hipLaunchKernelGGL(k_bounds, dim3(grid_n), dim3(256), 0, st, prims16, n, b.boxes, b.bbox_partial);
+    // only the Morton codes read the boxes in a default build of the index-keyed tree: centres in their place
+    const bool mids = build_keeps_centres_only(flags);
+    if (mids) hipLaunchKernelGGL(k_bounds<true>, dim3(grid_n), dim3(256), 0, st, prims16, n, b.boxes, b.bbox_partial);
+    else      hipLaunchKernelGGL(k_bounds<false>, dim3(grid_n), dim3(256), 0, st, prims16, n, b.boxes, b.bbox_partial);
     hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(1024), 0, st, b.bbox_partial, grid_n, b.bbox_enc);
     if (ev) PT_HIP(ctx, hipEventRecord(ev[PT_STAGE_BOUNDS + 1], st));
 
     const bool full = (flags & PT_BUILD_MORTON_FULL) != 0;
     const float cells = full ? 2097151.0f : (float)PT_MORTON_CODE_LENGTH_EACH;
     // the reference's codes have 15 bits: 32-bit keys halve the sort's key traffic
-    if (full) hipLaunchKernelGGL(k_morton<uint64_t>, dim3(grid_n), dim3(256), 0, st, b.boxes, n, b.bbox_enc, cells,
-                                 static_cast<uint64_t *>(b.morton));
-    else      hipLaunchKernelGGL(k_morton<uint32_t>, dim3(grid_n), dim3(256), 0, st, b.boxes, n, b.bbox_enc, cells,
-                                 static_cast<uint32_t *>(b.morton));
+#define PT_MORTON(K, M) hipLaunchKernelGGL((k_morton<K, M>), dim3(grid_n), dim3(256), 0, st, b.boxes, n, b.bbox_enc, cells, static_cast<K *>(b.morton))
+    if (full) { if (mids) PT_MORTON(uint64_t, true); else PT_MORTON(uint64_t, false); }
+    else      { if (mids) PT_MORTON(uint32_t, true); else PT_MORTON(uint32_t, false); }
+#undef PT_MORTON
     if (ev) PT_HIP(ctx, hipEventRecord(ev[PT_STAGE_MORTON + 1], st));
 
     // The reference quantises each axis to 0..21 (5 bits), so its codes occupy
@@ -1106,6 +1123,7 @@ int ptk_build(pt_context *ctx, unsigned flags)
     if (int rc = run_build(ctx, b, reinterpret_cast<const uint4 *>(ctx->d_prims), ctx->n, flags, ctx->ev, &ctx->sorted_buf)) return rc;
     ctx->morton_bits = full ? 64 : 32;
     ctx->sort_passes = full ? 8 : 2;
+    ctx->boxes_valid = !build_keeps_centres_only(flags);
     ctx->tree_height = 0;
     if (flags & PT_BUILD_TOPOLOGY_MORTON) {
         // the traversal stacks are sized by the height of the tree, which only the finished tree tells
@@ -1227,10 +1245,22 @@ static_assert(noalloc_need(PT_NOALLOC_MAX_PRIMS) <= PT_NOALLOC_SCRATCH_BYTES, "s
 
 // Fills ctx->d_tree (2n nodes in the reference's layout).  With PT_BUILD_KARRAS_LINKS the links are
 // then rewritten by the search-based kernel that follows radix_build_cs.hlsl: the same values.
+// The exports read the per-triangle boxes, which a default build does not keep: made here on first use.
+static int ensure_boxes(pt_context *ctx)
+{
+    if (ctx->boxes_valid) return PT_OK;
+    hipLaunchKernelGGL(k_bounds<false>, dim3((ctx->n + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4 *>(ctx->d_prims), ctx->n,
+                       ctx->d_boxes, ctx->d_bbox_partial);
+    PT_HIP(ctx, hipGetLastError());
+    ctx->boxes_valid = true;
+    return PT_OK;
+}
+
 int ptk_export_tree(pt_context *ctx)
 {
     const int n = ctx->n;
     hipStream_t st = ctx->stream;
+    if (int rc = ensure_boxes(ctx)) return rc;
     const int top = bit_length((unsigned)n);
     if (ctx->build_flags & PT_BUILD_TOPOLOGY_MORTON) {
         // n - 1 internal nodes: slots n - 1 and 2n stay zero
@@ -1253,6 +1283,7 @@ int ptk_export_tree(pt_context *ctx)
 
 int ptk_export_sorted(pt_context *ctx, pt_PrimitiveRayCS *d_out)
 {
+    if (int rc = ensure_boxes(ctx)) return rc;
     hipLaunchKernelGGL(k_export_sorted, dim3((ctx->n + 255) / 256), dim3(256), 0, ctx->stream,
                        ctx->d_vals[ctx->sorted_buf], ctx->d_boxes, ctx->n, d_out);
     PT_HIP(ctx, hipGetLastError());

@@ -127,6 +127,7 @@ struct pt_context {
     unsigned build_flags = 0;
     int capacity = 0;                 // primitives the buffers below were sized for
     BoxRec *d_boxes = nullptr;        // n
+    bool boxes_valid = false;         // false after a build that kept only the boxes' centres there
     unsigned *d_bbox_enc = nullptr;   // 6 order-preserving encodings + padding
     float *d_bbox_partial = nullptr;  // 6 floats per bounds workgroup
     uint64_t *d_keys[2] = {nullptr, nullptr};
