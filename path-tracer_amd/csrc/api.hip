@@ -42,6 +42,7 @@ static void read_knobs(Knobs &k)
     k.swap_t = env_int("PTAMD_SWAP_T", k.swap_t);
     k.shade_t = env_int("PTAMD_SHADE_T", k.shade_t);
     k.dual_leaf_t = env_int("PTAMD_DUAL_LEAF_T", k.dual_leaf_t);
+    k.sort_chained = env_int("PTAMD_SORT_CHAINED", k.sort_chained);
 }
 
 static int bit_length_u(unsigned v) { return v ? 32 - __builtin_clz(v) : 0; }

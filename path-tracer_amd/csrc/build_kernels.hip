@@ -187,6 +187,12 @@ __global__ __launch_bounds__(256) void k_morton(const BoxRec *__restrict__ boxes
 //             k_sort_scan (one workgroup per digit scans its row of counts)
 //             k_sort_scatter (wave64 ballot match -> stable ranks, LDS-staged
 //                             reorder, coalesced runs out)
+// Sorts of more than two passes (full-resolution codes) read their keys once per
+// pass instead of twice: k_sort_digit_counts counts every digit of every pass in
+// ONE sweep over the unsorted keys (the counts of a digit do not depend on the
+// order of the keys), and each pass is a single k_sort_scatter<CHAINED> launch
+// whose workgroups find their per-digit offsets by looking back over the tiles
+// before them (one status word per tile and digit) -- see chain_lookback.
 // ---------------------------------------------------------------------------
 template <typename K>
 __global__ __launch_bounds__(PT_SORT_THREADS) void k_sort_hist(const K *__restrict__ keys, int n, int shift,
@@ -244,23 +250,121 @@ __global__ __launch_bounds__(256) void k_sort_scan(uint32_t *__restrict__ block_
     if (t == 0) digit_total[d] = carry;
 }
 
-template <typename K, bool IOTA, bool KEYS_OUT>
+// All PASSES digit histograms of the keys in one sweep: per-workgroup counts in LDS, then one
+// global add per non-empty (pass, digit).  digit_total[PASSES][256] starts at zero.
+template <typename K, int PASSES>
+__global__ __launch_bounds__(256) void k_sort_digit_counts(const K *__restrict__ keys, int n, uint32_t *__restrict__ digit_total)
+{
+    __shared__ uint32_t h[PASSES * 256];
+    const int t = threadIdx.x;
+    for (int i = t; i < PASSES * 256; i += 256) h[i] = 0;
+    __syncthreads();
+    const long long stride = (long long)gridDim.x * 1024;
+    for (long long base = (long long)blockIdx.x * 1024; base < n; base += stride) {
+        K k[4];
+        bool valid[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {                   // four loads in flight
+            const long long g = base + r * 256 + t;
+            valid[r] = g < n;
+            k[r] = valid[r] ? keys[g] : (K)0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (valid[r]) {
+                const unsigned active = (unsigned)__popcll(__ballot(1));
+                const bool first_lane = (t & 63) == __builtin_amdgcn_readfirstlane(t & 63);
+#pragma unroll
+                for (int p = 0; p < PASSES; p++) {
+                    const unsigned d = (unsigned)(k[r] >> (8 * p)) & 255u;
+                    // a digit that all lanes share (the empty top bytes of short codes) is one add, not 64 serialised ones
+                    const unsigned d0 = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
+                    if (__all(d == d0)) { if (first_lane) atomicAdd(&h[p * 256 + d0], active); }
+                    else atomicAdd(&h[p * 256 + d], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PASSES; p++) {
+        const uint32_t c = h[p * 256 + t];
+        if (c) atomicAdd(&digit_total[p * 256 + t], c);
+    }
+}
+
+// Status word of (tile, digit) in a chained pass: bits 31..30 = 0 nothing yet, CH_AGG: bits 29..0 hold the tile's own count
+// of the digit, CH_PREFIX: they hold the count of this tile and all tiles before it.  One aligned 32-bit word written by ONE
+// agent-scope store and polled by agent-scope loads (both bypass the caches that other workgroups' stores do not refresh), so
+// the word is its own flag and no fence is needed.  Counts stay below 2^30 (the host checks n).
+constexpr uint32_t CH_AGG = 1u << 30, CH_PREFIX = 2u << 30, CH_MASK = CH_AGG - 1;
+constexpr unsigned CH_SPIN_LIMIT = 1u << 22;            // polls of one word before a workgroup gives up (seconds)
+constexpr int CH_TICKET_WORD = 8 * 256 + 16;            // in digit_total: one tile counter per pass
+constexpr int CH_ERROR_WORD = 8 * 256 + 32;             // in digit_total: set when a workgroup gave up
+__device__ __forceinline__ uint32_t chain_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void chain_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Number of keys with digit t in the tiles before `tile`: sums the counts of the preceding tiles, nearest first, until one
+// of them already knows its own prefix.  Tiles are numbered in the order in which workgroups START (a ticket counter), so
+// every tile before this one belongs to a workgroup that is running or has finished, and a tile publishes its own count
+// before it looks back: the wait always ends.  Four status words are fetched per round trip.  A workgroup that polls one
+// word CH_SPIN_LIMIT times sets the error word and goes on with what it has (positions then stay inside the output,
+// because a partial sum is never larger than the whole); the host reports the build as failed.
+__device__ __forceinline__ uint32_t chain_lookback(uint32_t *status, uint32_t tile, int t, uint32_t *error)
+{
+    uint32_t excl = 0;
+    long long j = (long long)tile - 1;
+    unsigned spins = 0;
+    while (j >= 0) {
+        uint32_t x[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = (j - k >= 0) ? chain_load(status + (size_t)(j - k) * 256 + t) : CH_PREFIX;
+        int used = 0;
+        bool done = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t flag = x[k] >> 30;
+            if (!done && used == k && flag != 0) { excl += x[k] & CH_MASK; used = k + 1; done = (flag == 2u); }
+        }
+        if (done) break;
+        j -= used;
+        if (used == 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > CH_SPIN_LIMIT) { atomicOr(error, 1u); break; }
+        }
+    }
+    return excl;
+}
+
+// CHAINED: `status` = one word per (tile, digit), all zero at launch; chain_ticket = the pass's tile counter (zero at
+// launch); digit_total = the digit counts of this pass (k_sort_digit_counts).  Otherwise block_off / digit_total come from
+// k_sort_hist / k_sort_scan and the tile is the workgroup's index.
+template <typename K, bool IOTA, bool KEYS_OUT, bool CHAINED>
 __global__ __launch_bounds__(PT_SORT_THREADS) void k_sort_scatter(
     const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     K *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int n, int shift,
-    const uint32_t *__restrict__ block_off, const uint32_t *__restrict__ digit_total, int nblocks)
+    const uint32_t *__restrict__ block_off, const uint32_t *__restrict__ digit_total, int nblocks,
+    uint32_t *status, uint32_t *chain_ticket, uint32_t *chain_error)
 {
     __shared__ uint32_t digit_gbase[256];               // first output slot of each digit
-    __shared__ K skeys[PT_SORT_TILE];                   // 16 or 32 KB
-    __shared__ uint32_t svals[PT_SORT_TILE];            // 16 KB
+    // 64-bit keys: keys and values go through the SAME 32 KB in turn (39 KB per workgroup, four workgroups per CU
+    // instead of two); 32-bit keys: 16 KB each, side by side
+    constexpr bool TWO_ROUNDS = sizeof(K) == 8;
+    __shared__ K skeys[PT_SORT_TILE];
+    __shared__ uint32_t svals_own[TWO_ROUNDS ? 1 : PT_SORT_TILE];
+    uint32_t *svals = TWO_ROUNDS ? reinterpret_cast<uint32_t *>(skeys) : svals_own;
     __shared__ uint32_t wave_hist[4][256];              //  4 KB
     __shared__ uint32_t digit_base[256];
+    __shared__ uint32_t tile_off[CHAINED ? 256 : 1];    // CHAINED: keys of the digit in the tiles before this one
     __shared__ uint32_t sh[5];
+    __shared__ uint32_t s_tile;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (CHAINED && t == 0) s_tile = atomicAdd(chain_ticket, 1u);
     for (int i = t; i < 4 * 256; i += PT_SORT_THREADS) (&wave_hist[0][0])[i] = 0;
     __syncthreads();
+    const uint32_t tile = CHAINED ? s_tile : blockIdx.x;
 
-    const long long tile_base = (long long)blockIdx.x * PT_SORT_TILE;
+    const long long tile_base = (long long)tile * PT_SORT_TILE;
     const long long wave_base = tile_base + (long long)wave * (PT_SORT_ITEMS * 64);
     const int tile_cnt = (int)min((long long)PT_SORT_TILE, (long long)n - tile_base);
 
@@ -274,7 +378,9 @@ __global__ __launch_bounds__(PT_SORT_THREADS) void k_sort_scatter(
         key[r] = valid ? keys_in[g] : (K)~(K)0;
         val[r] = IOTA ? (uint32_t)g : (valid ? vals_in[g] : 0u);
     }
-    volatile uint32_t *wh = wave_hist[wave];
+    // (an explicit LDS pointer: volatile accesses through a generic pointer are issued as flat_ instructions)
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_counter;
+    lds_counter *wh = (lds_counter *)wave_hist[wave];
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
     for (int r = 0; r < PT_SORT_ITEMS; r++) {
@@ -299,25 +405,56 @@ __global__ __launch_bounds__(PT_SORT_THREADS) void k_sort_scatter(
     {   // per digit: exclusive prefix over the four waves, then over the digits
         uint32_t c0 = wave_hist[0][t], c1 = wave_hist[1][t], c2 = wave_hist[2][t], c3 = wave_hist[3][t];
         uint32_t tot = c0 + c1 + c2 + c3, dummy;
+        // (the padding slots of a ragged last tile count as digit 255 here: no tile follows it)
+        if (CHAINED) chain_store(status + (size_t)tile * 256 + t, (tile == 0 ? CH_PREFIX : CH_AGG) | tot);
         wave_hist[0][t] = 0; wave_hist[1][t] = c0; wave_hist[2][t] = c0 + c1; wave_hist[3][t] = c0 + c1 + c2;
         digit_base[t] = block_excl_scan_256(tot, sh, &dummy);
         digit_gbase[t] = block_excl_scan_256(digit_total[t], sh, &dummy);
+        if (CHAINED) {
+            const uint32_t before = chain_lookback(status, tile, t, chain_error);
+            if (tile > 0) chain_store(status + (size_t)tile * 256 + t, CH_PREFIX | (before + tot));
+            tile_off[t] = before;
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < PT_SORT_ITEMS; r++) {
         uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
         uint32_t p = digit_base[d] + wave_hist[wave][d] + rank[r];
+        rank[r] = p;                                    // the slot inside the tile's sorted order
         skeys[p] = key[r];
-        svals[p] = val[r];
+        if (!TWO_ROUNDS) svals[p] = val[r];
     }
     __syncthreads();
-    for (int i = t; i < tile_cnt; i += PT_SORT_THREADS) {
-        K k = skeys[i];
-        uint32_t d = (uint32_t)(k >> shift) & 255u;
-        uint32_t dst = digit_gbase[d] + block_off[(size_t)d * nblocks + blockIdx.x] + ((uint32_t)i - digit_base[d]);
-        if (KEYS_OUT) keys_out[dst] = k;
-        vals_out[dst] = svals[i];
+    if (!TWO_ROUNDS) {
+        for (int i = t; i < tile_cnt; i += PT_SORT_THREADS) {
+            K k = skeys[i];
+            uint32_t d = (uint32_t)(k >> shift) & 255u;
+            uint32_t dst = digit_gbase[d] + (CHAINED ? tile_off[d] : block_off[(size_t)d * nblocks + blockIdx.x]) + ((uint32_t)i - digit_base[d]);
+            if (KEYS_OUT) keys_out[dst] = k;
+            vals_out[dst] = svals[i];
+        }
+    } else {
+        uint32_t dst[PT_SORT_ITEMS];
+#pragma unroll
+        for (int r = 0; r < PT_SORT_ITEMS; r++) {
+            const int i = t + r * PT_SORT_THREADS;
+            if (i < tile_cnt) {
+                K k = skeys[i];
+                uint32_t d = (uint32_t)(k >> shift) & 255u;
+                dst[r] = digit_gbase[d] + (CHAINED ? tile_off[d] : block_off[(size_t)d * nblocks + blockIdx.x]) + ((uint32_t)i - digit_base[d]);
+                if (KEYS_OUT) keys_out[dst[r]] = k;
+            }
+        }
+        __syncthreads();                                // every key has been read: the buffer takes the values
+#pragma unroll
+        for (int r = 0; r < PT_SORT_ITEMS; r++) svals[rank[r]] = val[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PT_SORT_ITEMS; r++) {
+            const int i = t + r * PT_SORT_THREADS;
+            if (i < tile_cnt) vals_out[dst[r]] = svals[i];
+        }
     }
 }
 
@@ -968,8 +1105,45 @@ static int radix_sort_passes(hipStream_t st, const K *keys, int n, int passes, K
         const bool first = (p == 0), last = (p == passes - 1) && !keys_last;
         hipLaunchKernelGGL(k_sort_hist<K>, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, n, shift, block_hist, nblocks);
         hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, st, block_hist, dtot, nblocks);
-#define PT_SCATTER(I, KO) hipLaunchKernelGGL((k_sort_scatter<K, I, KO>), dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, vin, \
-                                             kbuf[out], vbuf[out], n, shift, block_hist, dtot, nblocks)
+#define PT_SCATTER(I, KO) hipLaunchKernelGGL((k_sort_scatter<K, I, KO, false>), dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, vin, \
+                                             kbuf[out], vbuf[out], n, shift, block_hist, dtot, nblocks, nullptr, nullptr, nullptr)
+        if (first) { if (last) PT_SCATTER(true, false); else PT_SCATTER(true, true); }
+        else       { if (last) PT_SCATTER(false, false); else PT_SCATTER(false, true); }
+#undef PT_SCATTER
+        kin = kbuf[out];
+        vin = vbuf[out];
+        out ^= 1;
+    }
+    return out ^ 1;
+}
+
+// The same sort with ONE read of the keys per pass (k_sort_digit_counts, then k_sort_scatter<CHAINED>): `status` is the
+// block_hist buffer (256 words per tile), digit_total the 8 * 256 + 512 words of the build (counts, tile counters, error
+// word).  For n < 2^30.  Used for the eight passes over full-resolution codes (50 M keys: 3.4 ms against 4.6 ms); the two
+// short passes over the reference's 15-bit codes stay with the counting pass: a pass of 50 us pays more for the start of
+// the look-back chain than for reading its 4-byte keys twice (10 M keys: 0.21 ms chained against 0.15 ms).
+static bool sort_chained_applies(const pt_context *ctx, int n, int passes)
+{
+    return ctx->knobs.sort_chained && passes > 2 && passes <= 8 && (unsigned)n < CH_AGG;
+}
+
+template <typename K, int PASSES>
+static int radix_sort_chained(hipStream_t st, const K *keys, int n, K *const kbuf[2], uint32_t *const vbuf[2],
+                              uint32_t *status, uint32_t *digit_total, int num_cus, bool keys_last)
+{
+    const int nblocks = (n + PT_SORT_TILE - 1) / PT_SORT_TILE;
+    if (hipMemsetAsync(digit_total, 0, (8 * 256 + 512) * sizeof(uint32_t), st) != hipSuccess) return -1;
+    const int count_grid = std::min((n + 1023) / 1024, num_cus * 8);
+    hipLaunchKernelGGL((k_sort_digit_counts<K, PASSES>), dim3(count_grid), dim3(256), 0, st, keys, n, digit_total);
+    const K *kin = keys;
+    const uint32_t *vin = nullptr;
+    int out = 0;
+    for (int p = 0; p < PASSES; p++) {
+        const bool first = (p == 0), last = (p == PASSES - 1) && !keys_last;
+        if (hipMemsetAsync(status, 0, (size_t)nblocks * 256 * sizeof(uint32_t), st) != hipSuccess) return -1;
+#define PT_SCATTER(I, KO) hipLaunchKernelGGL((k_sort_scatter<K, I, KO, true>), dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, vin, \
+                                             kbuf[out], vbuf[out], n, 8 * p, nullptr, digit_total + 256 * p, nblocks, status, \
+                                             digit_total + CH_TICKET_WORD + p, digit_total + CH_ERROR_WORD)
         if (first) { if (last) PT_SCATTER(true, false); else PT_SCATTER(true, true); }
         else       { if (last) PT_SCATTER(false, false); else PT_SCATTER(false, true); }
 #undef PT_SCATTER
@@ -1006,7 +1180,7 @@ int ptk_order_pixels(pt_context *ctx, int shift)
 static bool build_keeps_centres_only(unsigned flags) { return (flags & (PT_BUILD_TREE_ONLY | PT_BUILD_TOPOLOGY_MORTON)) == 0; }
 
 static int run_build(pt_context *ctx, const BuildBufs &b, const uint4 *prims16, int n, unsigned flags,
-                     hipEvent_t *ev, int *sorted_buf)
+                     hipEvent_t *ev, int *sorted_buf, bool chained = false)
 {
     hipStream_t st = ctx->stream;
     const int grid_n = (n + 255) / 256;
@@ -1035,8 +1209,14 @@ static int run_build(pt_context *ctx, const BuildBufs &b, const uint4 *prims16, 
     const bool by_codes = (flags & PT_BUILD_TOPOLOGY_MORTON) != 0;      // the tree search reads the sorted codes
     if (full) {
         uint64_t *const kb[2] = {static_cast<uint64_t *>(b.keys[0]), static_cast<uint64_t *>(b.keys[1])};
-        *sorted_buf = radix_sort_passes<uint64_t>(st, static_cast<const uint64_t *>(b.morton), n, passes, kb, b.vals,
-                                                  b.block_hist, b.digit_total, by_codes);
+        if (chained) {
+            *sorted_buf = radix_sort_chained<uint64_t, 8>(st, static_cast<const uint64_t *>(b.morton), n, kb, b.vals,
+                                                          b.block_hist, b.digit_total, ctx->num_cus, by_codes);
+            if (*sorted_buf < 0) PT_FAIL(ctx, PT_ERR_HIP, "pt_build: hipMemsetAsync of the sort's status words failed");
+        } else {
+            *sorted_buf = radix_sort_passes<uint64_t>(st, static_cast<const uint64_t *>(b.morton), n, passes, kb, b.vals,
+                                                      b.block_hist, b.digit_total, by_codes);
+        }
     } else {
         uint32_t *const kb[2] = {static_cast<uint32_t *>(b.keys[0]), static_cast<uint32_t *>(b.keys[1])};
         *sorted_buf = radix_sort_passes<uint32_t>(st, static_cast<const uint32_t *>(b.morton), n, passes, kb, b.vals,
@@ -1120,9 +1300,17 @@ int ptk_build(pt_context *ctx, unsigned flags)
     b.wide = ctx->d_wide; b.chunk = ctx->d_chunk; b.shade = ctx->d_shade; b.tri = ctx->d_tri_sorted;
     b.links = ctx->d_links;
     const bool full = (flags & PT_BUILD_MORTON_FULL) != 0;
-    if (int rc = run_build(ctx, b, reinterpret_cast<const uint4 *>(ctx->d_prims), ctx->n, flags, ctx->ev, &ctx->sorted_buf)) return rc;
+    const bool chained = full && sort_chained_applies(ctx, ctx->n, 8);
+    if (int rc = run_build(ctx, b, reinterpret_cast<const uint4 *>(ctx->d_prims), ctx->n, flags, ctx->ev, &ctx->sorted_buf, chained)) return rc;
     ctx->morton_bits = full ? 64 : 32;
     ctx->sort_passes = full ? 8 : 2;
+    if (chained) {
+        // a workgroup of a chained pass that gave up waiting leaves a wrong order behind: the build has failed
+        unsigned gave_up = 0;
+        PT_HIP(ctx, hipMemcpyAsync(&gave_up, ctx->d_digit_total + CH_ERROR_WORD, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (gave_up) PT_FAIL(ctx, PT_ERR_HIP, "pt_build: a sorting workgroup gave up waiting for the tiles before it (PTAMD_SORT_CHAINED=0 selects the two-read passes)");
+    }
     ctx->boxes_valid = !build_keeps_centres_only(flags);
     ctx->tree_height = 0;
     if (flags & PT_BUILD_TOPOLOGY_MORTON) {

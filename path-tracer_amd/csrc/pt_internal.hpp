@@ -107,6 +107,7 @@ struct Knobs {
     int gen_lds_entries = 0;            // PTAMD_GEN_LDS_ENTRIES: cap of the LDS part of the explicit traversal stack (0: what fits)
     int pair_min_mib = 24;              // PTAMD_PAIR_MIN_MIB: child lines only when the plain records take at least this much
     int pair_max_mib = 65536;           // PTAMD_PAIR_MAX_MIB: largest array of child lines (0: never use it)
+    int sort_chained = 1;               // PTAMD_SORT_CHAINED: sorts of more than two passes read their keys once per pass (0: separate counting pass per pass)
 };
 
 struct pt_context {

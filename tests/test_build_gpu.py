@@ -168,6 +168,30 @@ def test_full_resolution_codes_eight_passes(gpu_ctx_factory):
     assert np.array_equal(t["index"][n:], perm)
 
 
+@pytest.mark.parametrize("n", [1, 2, 4095, 4097, 12289, 300007])
+def test_eight_pass_sort_single_read_and_two_read_passes_agree(gpu_ctx_factory, monkeypatch, n):
+    """The eight passes over full-resolution codes read their keys once per pass (one count of all digits up front, then
+    look-back over the tiles' status words); PTAMD_SORT_CHAINED=0 (read at pt_create) selects a counting pass per pass.
+    Both must give numpy's stable order, also with heavy ties (triangles snapped onto a coarse grid share their codes)
+    and for a ragged last tile."""
+    prims = make_soup(n, seed=500 + n)
+    if n > 4097:   # half of the triangles share 64 centres: long runs of equal keys across many tiles
+        snap = prims["vertices"]["pos"][: n // 2]
+        snap[...] = np.floor(snap * 4) / 4
+    perms = []
+    for chained in ("1", "0"):
+        monkeypatch.setenv("PTAMD_SORT_CHAINED", chained)
+        ctx = gpu_ctx_factory()
+        ctx.upload_primitives(prims)
+        ctx.build(ptamd.PT_BUILD_MORTON_FULL | ptamd.PT_BUILD_TREE_ONLY)
+        ctx.build(ptamd.PT_BUILD_MORTON_FULL | ptamd.PT_BUILD_TREE_ONLY)      # status words and counters are reset per build
+        assert ctx.build_times()["sort_passes"] == 8
+        codes = ctx.morton()
+        perms.append(ctx.permutation())
+        assert np.array_equal(perms[-1], np.argsort(codes, kind="stable").astype(np.int32))
+    assert np.array_equal(perms[0], perms[1])
+
+
 def test_tree_export_is_on_demand_and_repeatable(gpu_ctx_factory, golden):
     """The reference-layout tree is derived from the traversal records when asked for: asking
     twice, or after tracing, gives the same bytes; traversal works without ever asking."""
