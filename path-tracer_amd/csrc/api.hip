@@ -43,6 +43,7 @@ static void read_knobs(Knobs &k)
     k.shade_t = env_int("PTAMD_SHADE_T", k.shade_t);
     k.dual_leaf_t = env_int("PTAMD_DUAL_LEAF_T", k.dual_leaf_t);
     k.sort_chained = env_int("PTAMD_SORT_CHAINED", k.sort_chained);
+    k.extra_wave = env_int("PTAMD_EXTRA_WAVES", k.extra_wave);
 }
 
 static int bit_length_u(unsigned v) { return v ? 32 - __builtin_clz(v) : 0; }
@@ -74,6 +75,7 @@ static void free_build(pt_context *ctx)
     dev_free(ctx->d_pair); ctx->pair_cap = 0; ctx->pair_valid = false;
     dev_free(ctx->d_links); ctx->links_cap = 0;
     dev_free(ctx->d_gstack); ctx->gstack_cap = 0;
+    dev_free(ctx->d_xstack);
     dev_free(ctx->d_chunk);
     dev_free(ctx->d_shade);
     dev_free(ctx->d_tri_sorted);

@@ -107,6 +107,7 @@ struct Knobs {
     int gen_lds_entries = 0;            // PTAMD_GEN_LDS_ENTRIES: cap of the LDS part of the explicit traversal stack (0: what fits)
     int pair_min_mib = 24;              // PTAMD_PAIR_MIN_MIB: child lines only when the plain records take at least this much
     int pair_max_mib = 65536;           // PTAMD_PAIR_MAX_MIB: largest array of child lines (0: never use it)
+    int extra_wave = 16;                // PTAMD_EXTRA_WAVES: most waves per CU that k_trace_dual runs beyond those whose stacks fit in LDS beside the tree (their stacks: global memory); 0: none
     int sort_chained = 1;               // PTAMD_SORT_CHAINED: sorts of more than two passes read their keys once per pass (0: separate counting pass per pass)
 };
 
@@ -143,6 +144,7 @@ struct pt_context {
     int tree_height = 0;              // PT_BUILD_TOPOLOGY_MORTON: internal nodes on the longest root-to-leaf path
     uint2 *d_gstack = nullptr;        // traversal-stack entries beyond the LDS part (Morton-keyed trees deeper than that)
     size_t gstack_cap = 0;            // entries
+    float *d_xstack = nullptr;        // stack entries of k_trace_dual's waves beyond the LDS stacks: 16 waves x 32 levels x 64 lanes per CU
     pt_TreeNode *d_tree = nullptr;    // 2n+1, allocated and filled by the first pt_download_tree after a build
     bool tree_exported = false;
     WideNode *d_wide = nullptr;       // n

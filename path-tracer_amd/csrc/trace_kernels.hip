@@ -910,52 +910,25 @@ constexpr int P_START = 0, P_READY = 1, P_DONE = 2, P_NONE = 3;
 
 __device__ __forceinline__ void lane_swap(float &a, float &b) { const float t = a; a = b; b = t; }
 
-// LDSN = false: index-keyed trees read as plain records from global memory, their upper levels from LDS (TopLevels)
-template <bool COUNT, bool LDSN>
-__global__ __launch_bounds__(1024) void k_trace_dual(SceneView sc, const TriIsect *__restrict__ tri_sorted, int levels,
-                                              unsigned n_slots,
-                                              const uint8_t *__restrict__ diffuse_tex,
-                                              const float4 *__restrict__ normal_tex,
-                                              const float4 *__restrict__ world_tex,
-                                              uint32_t first_frame, uint32_t count,
-                                              float4 *__restrict__ samples, DevCounters *__restrict__ counters,
-                                              unsigned *__restrict__ work_counter,
-                                              const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
-                                              uint32_t chunk, Tuning tune, TopLevels top)
+// One wave's share of k_trace_dual (below), after the workgroup has filled its LDS.  XW: this wave keeps its per-level stack
+// entries in global memory (`xst`: this lane's column of `levels` rows of 64 floats) instead of LDS -- the one wave more than
+// the LDS beside the tree has stack room for.  The function is instantiated once per kind of wave, each copy with its own
+// local state, so the waves with their stack in LDS run an instruction stream that never tests the wave's kind.
+template <bool COUNT, bool LDSN, bool XW>
+__device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *__restrict__ tri_sorted, const int levels,
+                                           const unsigned n_slots,
+                                           const uint8_t *__restrict__ diffuse_tex,
+                                           const float4 *__restrict__ normal_tex,
+                                           const float4 *__restrict__ world_tex,
+                                           const uint32_t first_frame, const uint32_t count,
+                                           float4 *__restrict__ samples, DevCounters *__restrict__ counters,
+                                           unsigned *__restrict__ work_counter,
+                                           const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
+                                           const uint32_t chunk, const Tuning &tune, const TopLevels &top,
+                                           const float4 *lds_nodes, const float4 *lds_mats, const float4 *lds_matq, const int *lds_off,
+                                           float *stack, const int nthreads, float *__restrict__ xst)
 {
-    // LDS as in k_trace_persistent: node records (all, or the upper levels), materials, material quotients, (the level
-    // offsets of the upper levels,) one float per level and lane
-    extern __shared__ __attribute__((aligned(16))) float4 lds_nodes[];
     const int n = sc.n;
-    const int nthreads = blockDim.x;
-    float4 *lds_mats = lds_nodes + (LDSN ? 3 * n : 3 * top.nodes);
-    float4 *lds_matq = lds_mats + 3 * MAT_SLOTS;
-    int *lds_off = reinterpret_cast<int *>(lds_matq + MAT_SLOTS);
-    float *stack = reinterpret_cast<float *>(lds_matq + MAT_SLOTS + (LDSN ? 0 : 9)) + threadIdx.x;   // level L at stack[(L-1) * nthreads]
-    if (LDSN) {
-        for (int i = threadIdx.x; i < 3 * n; i += nthreads) {
-            const int node = i / 3, part = i - 3 * node;
-            lds_nodes[i] = reinterpret_cast<const float4 *>(&sc.wide[node])[part];
-        }
-    } else {
-        if (threadIdx.x < 33) lds_off[threadIdx.x] = top.off[threadIdx.x];
-        for (int i = threadIdx.x; i < top.nodes; i += nthreads) {
-            // compact index -> (level, block) -> node id, as in k_trace_persistent
-            int k = levels;
-            while (k > top.k0 && i >= top.off[k - 1]) k--;
-            const long long bb = i - top.off[k];
-            const int id = ((bb & 1) == 0 && ((bb + 1) << k) <= (long long)n) ? (int)(((bb + 1) << k) - 1) : (int)(bb << k);
-            const float4 *src = reinterpret_cast<const float4 *>(&sc.wide[id]);
-            lds_nodes[3 * i] = src[0]; lds_nodes[3 * i + 1] = src[1]; lds_nodes[3 * i + 2] = src[2];
-        }
-    }
-    if (threadIdx.x < 3 * MAT_SLOTS) lds_mats[threadIdx.x] = reinterpret_cast<const float4 *>(sc.cb->mats)[threadIdx.x];
-    if (threadIdx.x < MAT_SLOTS) {
-        const float4 *mp = reinterpret_cast<const float4 *>(sc.cb->mats) + 3 * threadIdx.x;
-        lds_matq[threadIdx.x] = material_quotients(mp[0], mp[1], mp[2]);
-    }
-    __syncthreads();
-
     // STARVE_T: lanes with nothing to traverse in either slot; SHADE_T: parked slots waiting for a refill round;
     // SWAP_T: lanes whose ray ended while a parked ray is ready
     const int STARVE_T = tune.refill_t, SHADE_T = tune.shade_t, LEAF_T = tune.leaf_t, ITR_LIMIT = tune.itr_limit, SWAP_T = tune.swap_t;
@@ -1196,7 +1169,11 @@ __global__ __launch_bounds__(1024) void k_trace_dual(SceneView sc, const TriIsec
                     const int k = cur_k, half = 1 << (k - 1);
                     const int sr = cur_s + half, e = min(sr + half - 1, n);
                     const int kr = 32 - __clz(sr ^ e);
-                    if (hl && hr) { stack[__umul24((unsigned)(k - 1), (unsigned)nthreads)] = tr; pending |= 1u << k; }
+                    if (hl && hr) {
+                        if (XW) xst[(k - 1) * 64] = tr;
+                        else stack[__umul24((unsigned)(k - 1), (unsigned)nthreads)] = tr;
+                        pending |= 1u << k;
+                    }
                     cur_k = hl ? k - 1 : (hr ? kr : K_POP);
                     cur_id = hl ? sr - 1 : sr;
                     cur_s = hl ? cur_s : sr;
@@ -1209,7 +1186,7 @@ __global__ __launch_bounds__(1024) void k_trace_dual(SceneView sc, const TriIsec
                     } else {
                         const int L = __ffs((int)pending) - 1;
                         pending &= pending - 1;
-                        const float t_entry = stack[__umul24((unsigned)(L - 1), (unsigned)nthreads)];
+                        const float t_entry = XW ? xst[(L - 1) * 64] : stack[__umul24((unsigned)(L - 1), (unsigned)nthreads)];
                         if (t_entry <= current_t) {
                             const int sa = (cur_s >> L) << L, half = 1 << (L - 1);
                             const int sr = sa + half, e = min(sa + 2 * half - 1, n);
@@ -1274,6 +1251,66 @@ __global__ __launch_bounds__(1024) void k_trace_dual(SceneView sc, const TriIsec
     if (COUNT && lane == 0) {
         for (int k = 0; k < 10; k++) atomicAdd(&counters->sched[k], sched[k]);
     }
+}
+
+// LDSN = false: index-keyed trees read as plain records from global memory, their upper levels from LDS (TopLevels)
+template <bool COUNT, bool LDSN>
+__global__ __launch_bounds__(1024) void k_trace_dual(SceneView sc, const TriIsect *__restrict__ tri_sorted, int levels,
+                                              unsigned n_slots,
+                                              const uint8_t *__restrict__ diffuse_tex,
+                                              const float4 *__restrict__ normal_tex,
+                                              const float4 *__restrict__ world_tex,
+                                              uint32_t first_frame, uint32_t count,
+                                              float4 *__restrict__ samples, DevCounters *__restrict__ counters,
+                                              unsigned *__restrict__ work_counter,
+                                              const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
+                                              uint32_t chunk, Tuning tune, TopLevels top, int lds_threads, float *__restrict__ xstack)
+{
+    // LDS as in k_trace_persistent: node records (all, or the upper levels), materials, material quotients, (the level
+    // offsets of the upper levels,) one float per level and lane
+    extern __shared__ __attribute__((aligned(16))) float4 lds_nodes[];
+    const int n = sc.n;
+    const int nthreads = blockDim.x;
+    float4 *lds_mats = lds_nodes + (LDSN ? 3 * n : 3 * top.nodes);
+    float4 *lds_matq = lds_mats + 3 * MAT_SLOTS;
+    int *lds_off = reinterpret_cast<int *>(lds_matq + MAT_SLOTS);
+    float *stack = reinterpret_cast<float *>(lds_matq + MAT_SLOTS + (LDSN ? 0 : 9)) + threadIdx.x;   // level L at stack[(L-1) * nthreads]
+    if (LDSN) {
+        for (int i = threadIdx.x; i < 3 * n; i += nthreads) {
+            const int node = i / 3, part = i - 3 * node;
+            lds_nodes[i] = reinterpret_cast<const float4 *>(&sc.wide[node])[part];
+        }
+    } else {
+        if (threadIdx.x < 33) lds_off[threadIdx.x] = top.off[threadIdx.x];
+        for (int i = threadIdx.x; i < top.nodes; i += nthreads) {
+            // compact index -> (level, block) -> node id, as in k_trace_persistent
+            int k = levels;
+            while (k > top.k0 && i >= top.off[k - 1]) k--;
+            const long long bb = i - top.off[k];
+            const int id = ((bb & 1) == 0 && ((bb + 1) << k) <= (long long)n) ? (int)(((bb + 1) << k) - 1) : (int)(bb << k);
+            const float4 *src = reinterpret_cast<const float4 *>(&sc.wide[id]);
+            lds_nodes[3 * i] = src[0]; lds_nodes[3 * i + 1] = src[1]; lds_nodes[3 * i + 2] = src[2];
+        }
+    }
+    if (threadIdx.x < 3 * MAT_SLOTS) lds_mats[threadIdx.x] = reinterpret_cast<const float4 *>(sc.cb->mats)[threadIdx.x];
+    if (threadIdx.x < MAT_SLOTS) {
+        const float4 *mp = reinterpret_cast<const float4 *>(sc.cb->mats) + 3 * threadIdx.x;
+        lds_matq[threadIdx.x] = material_quotients(mp[0], mp[1], mp[2]);
+    }
+    __syncthreads();
+
+    // waves beyond `lds_threads` keep their stack entries in global memory: `levels` rows of 64 floats per wave, which
+    // stay in this CU's L1
+    if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= lds_threads) {
+        const size_t xwave = (size_t)blockIdx.x * ((blockDim.x - lds_threads) >> 6) + ((threadIdx.x - lds_threads) >> 6);
+        dual_paths<COUNT, LDSN, true>(sc, tri_sorted, levels, n_slots, diffuse_tex, normal_tex, world_tex, first_frame, count, samples, counters,
+                                      work_counter, order, pixel_work, chunk, tune, top, lds_nodes, lds_mats, lds_matq, lds_off, stack, lds_threads,
+                                      xstack + xwave * 64 * (size_t)levels + (threadIdx.x & 63));
+    }
+    else
+        dual_paths<COUNT, LDSN, false>(sc, tri_sorted, levels, n_slots, diffuse_tex, normal_tex, world_tex, first_frame, count, samples, counters,
+                                       work_counter, order, pixel_work, chunk, tune, top, lds_nodes, lds_mats, lds_matq, lds_off, stack, lds_threads,
+                                       nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -1922,8 +1959,11 @@ static size_t stack_bytes(const pt_context *ctx)
 
 // Largest workgroup (multiple of 64, at most 1024 threads) whose per-level stack fits
 // beside the node records in the CU's 160 KiB of LDS; 0 when the tree does not fit.
-// LDS residency pays while at least eight waves fit beside the tree (measured: a 2800-triangle soup breaks even at 8
-// waves, a 3000-triangle one runs 25 % slower at 5 waves than from global memory at 16)
+// LDS residency pays while at least eight waves fit beside the tree (measured with the single-path kernel: a 2800-triangle
+// soup breaks even at 8 waves, a 3000-triangle one runs 25 % slower at 5 waves than from global memory at 16).  k_trace_dual,
+// which fills the workgroup up to 1024 threads with waves whose stacks are in global memory, would still gain down to 5
+// LDS waves (scene04 padded to 3000 triangles: 166 ms per 128 frames against 184 ms from global memory; break-even at 4),
+// but short launches run the single-path kernel, so the limit stays.
 constexpr int LDS_TREE_MIN_THREADS = 512;
 
 static int lds_resident_threads(const pt_context *ctx, int *levels_out, size_t *bytes_out)
@@ -2197,14 +2237,20 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             if ((lds_nodes || (!gen && !use_pair)) && !near_first && kn.dual && chunk >= (unsigned long long)kn.dual_min_chunk) {
                 // k_trace_dual: slots 30, 31 (tree in LDS), 18, 19 (plain records from global memory)
                 Tuning dt = tune;
+                // A tree in LDS leaves stack room for `threads` lanes; the waves up to 1024 threads (scene04: one, the sixteenth)
+                // run too, with their stack entries in global memory: 115 -> 109 ms per 128 frames of scene04.
+                int xthreads = lds_nodes ? 1024 - threads : 0;
+                if (xthreads > 64 * kn.extra_wave) xthreads = 64 * kn.extra_wave;
+                if (xthreads && !ctx->d_xstack)      // 16 waves x 32 levels x 64 lanes per CU: every case
+                    PT_HIP(ctx, hipMalloc((void **)&ctx->d_xstack, (size_t)ctx->num_cus * 16 * 32 * 64 * sizeof(float)));
                 dt.refill_t = kn.dual_refill_t;
                 dt.leaf_t = kn.dual_leaf_t;
 #define PT_LAUNCH_DUAL(SLOT, C, L) do { \
                 if (int rc_ = ensure_lds_limit(ctx, SLOT, &k_trace_dual<C, L>, lds_bytes)) return rc_; \
                 if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream)); \
-                hipLaunchKernelGGL((k_trace_dual<C, L>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
+                hipLaunchKernelGGL((k_trace_dual<C, L>), dim3(ctx->num_cus), dim3(threads + xthreads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
                     n_slots, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, ctx->d_samples, ctx->d_counters, ctx->d_work, \
-                    order, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, (uint32_t)chunk, dt, top); } while (0)
+                    order, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, (uint32_t)chunk, dt, top, threads, ctx->d_xstack); } while (0)
                 if (lds_nodes) { if (ctx->detailed) PT_LAUNCH_DUAL(31, true, true); else PT_LAUNCH_DUAL(30, false, true); }
                 else           { if (ctx->detailed) PT_LAUNCH_DUAL(19, true, false); else PT_LAUNCH_DUAL(18, false, false); }
 #undef PT_LAUNCH_DUAL

@@ -443,6 +443,27 @@ def test_full_size_frames_bit_exact(gpu_ctx_factory, golden, scene):
     assert ctx.counters()["rays"] == rays
 
 
+@pytest.mark.parametrize("extra_waves", ["16", "0"])
+def test_full_size_two_paths_per_lane_with_and_without_extra_waves(gpu_ctx_factory, golden, monkeypatch, extra_waves):
+    """scene04's tree leaves LDS room for the stacks of 15 waves; k_trace_dual runs a sixteenth whose stack entries live in
+    global memory (PTAMD_EXTRA_WAVES=0: 15 waves only).  At 1162x1008 every wave of every CU gets work, so both kinds of
+    wave are compared with the oracle: every pixel of three frames, and all counters."""
+    W, H = 1162, 1008
+    monkeypatch.setenv("PTAMD_EXTRA_WAVES", extra_waves)
+    ctx = _ctx_with_schedule(gpu_ctx_factory, monkeypatch, "dual")
+    sc, gb, _ = _setup(ctx, golden["scene04"], W, H)
+    seeds = ptamd.frame_seeds(1, 40, 3)
+    ctx.set_detailed_counters(True)
+    ctx.trace_frames(40, seeds, ptamd.PT_ACCUM_LINEAR)
+    acc = np.zeros((H, W, 4), np.float32)
+    tot = dict(paths=0, rays=0, node_visits=0, box_tests=0, tri_tests=0)
+    for f in range(3):
+        c = orc.trace_frame_linear(sc, gb, 40 + f, seeds[f], acc)
+        tot = {k: tot[k] + c[k] for k in tot}
+    assert np.array_equal(_bits(ctx.linear_sum()), _bits(acc))
+    assert ctx.counters() == tot
+
+
 def test_full_size_many_frames_properties(gpu_ctx_factory, golden):
     """scene04, 1162x1008, 256 frames: the same frames as one launch, as eight launches, under
     both schedules and in literal vs linear mode; linear alpha counts the samples; modes agree to the documented tolerance."""
