@@ -854,7 +854,8 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                 if (COUNT) { sched[2]++; sched[3] += __popcll(leaf_mask); }
                 if (at_leaf) {
                     const float4 *tp = reinterpret_cast<const float4 *>(&tri_sorted[cur_s]);
-                    const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    asm volatile("" : "+v"(t0.x), "+v"(t0.y), "+v"(t0.z));      // all three loads leave together (see k_trace_dual)
                     if (COUNT) cnt.tri_tests++;
                     // ray_tracing.hlsl:167-189
                     const pt_f3 a = pt_mk3(t0.x, t0.y, t0.z), e_1 = pt_mk3(t1.x, t1.y, t1.z), e_2 = pt_mk3(t2.x, t2.y, t2.z);
@@ -1216,7 +1217,10 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
                 if (COUNT) { sched[2]++; sched[3] += __popcll(leaf_mask); }
                 if (at_leaf) {
                     const float4 *tp = reinterpret_cast<const float4 *>(&tri_sorted[cur_s]);
-                    const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    // all three loads leave together: left to itself the compiler sinks the first one behind the determinant test, and a
+                    // triangle that passes it waits for memory twice
+                    asm volatile("" : "+v"(t0.x), "+v"(t0.y), "+v"(t0.z));
                     if (COUNT) cnt.tri_tests++;
                     // ray_tracing.hlsl:167-189
                     const pt_f3 a = pt_mk3(t0.x, t0.y, t0.z), e_1 = pt_mk3(t1.x, t1.y, t1.z), e_2 = pt_mk3(t2.x, t2.y, t2.z);
@@ -1647,7 +1651,8 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
             if (leaf_mask != 0 && (__popcll(leaf_mask) >= LEAF_T || ballot64(cur_k >= 1) == 0)) {
                 if (at_leaf) {
                     const float4 *tp = reinterpret_cast<const float4 *>(&tri_sorted[cur_s]);
-                    const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    float4 t0 = tp[0], t1 = tp[1], t2 = tp[2];
+                    asm volatile("" : "+v"(t0.x), "+v"(t0.y), "+v"(t0.z));      // all three loads leave together (see k_trace_dual)
                     if (COUNT) cnt.tri_tests++;
                     // ray_tracing.hlsl:167-189
                     const pt_f3 a = pt_mk3(t0.x, t0.y, t0.z), e_1 = pt_mk3(t1.x, t1.y, t1.z), e_2 = pt_mk3(t2.x, t2.y, t2.z);
