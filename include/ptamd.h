@@ -79,7 +79,9 @@ int pt_set_constants(pt_context *ctx, const pt_CB_Radix *cb);
  * is flat (0/0 in structs.hpp:92-97) quantises to cell 0, which is what the reference's x86 float ->
  * integer conversion leaves in the bits it interleaves. */
 #define PT_BUILD_DEFAULT        0u
-#define PT_BUILD_MORTON_FULL    1u   /* NON-PARITY: quantise to 2^21 cells per axis instead of the reference's 22 */
+#define PT_BUILD_MORTON_FULL    1u   /* NON-PARITY: quantise to 2^21 cells per axis instead of the reference's 22.
+                                        pt_build synchronises the stream with this flag (it reads back whether every
+                                        workgroup of the eight-pass sort found the tiles before it; PT_ERR_HIP if not) */
 #define PT_BUILD_KARRAS_LINKS   4u   /* pt_download_tree also runs the search-based link kernel (the direct
                                         counterpart of radix_build_cs.hlsl) over the links it has written from
                                         the closed form of the index-keyed tree -- same values */
@@ -310,7 +312,11 @@ int pt_reset_counters(pt_context *ctx);
  * launches with at least PTAMD_DUAL_MIN_CHUNK = 4 frames per work item use),
  * PTAMD_DUAL_REFILL_T / PTAMD_SHADE_T / PTAMD_SWAP_T / PTAMD_DUAL_LEAF_T (wave-vote thresholds of the latter: 4 / 48 / 4 / 8),
  * PTAMD_GEN_LDS_ENTRIES (PT_BUILD_TOPOLOGY_MORTON trees: entries of each lane's traversal stack kept in LDS, the deeper
- * ones live in global memory; default: as many as fit, 19 at 1024 threads). */
+ * ones live in global memory; default: as many as fit, 19 at 1024 threads),
+ * PTAMD_EXTRA_WAVES (trees in LDS, two-path kernel: most waves per CU that run beyond those whose traversal stacks fit in
+ * LDS beside the tree, with their stack entries in global memory; 16 = fill the workgroup to 1024 threads, 0 = none),
+ * PTAMD_SORT_CHAINED=0 (PT_BUILD_MORTON_FULL: a counting pass and a scan before each of the eight radix passes instead of
+ * one count of all digits up front and passes that find their offsets by looking back over the tiles before them). */
 
 /* device-side duration of the trace kernel of every launch since timing was enabled (or since the
  * last pt_get_trace_times): HIP events on the context's stream around the persistent trace kernel
