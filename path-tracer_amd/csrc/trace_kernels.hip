@@ -412,57 +412,27 @@ constexpr int EXPANSIONS = PT_EXPANSIONS;      // node expansions per pass of th
 // GEN: the tree has explicit child ids (PT_BUILD_TOPOLOGY_MORTON: no closed form) and an explicit per-lane stack
 // of (node, entry distance) pairs: `levels` then is the number of stack entries held in LDS, deeper entries go to
 // `gstack` (entry e of lane L of workgroup B at gstack[(e - levels) * lanes_total + B * blockDim + L]).
-template <bool COUNT, bool LDSN, bool NEAR, bool PAIR = false, bool GEN = false>
-__global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const TriIsect *__restrict__ tri_sorted, int levels,
-                                                    uint2 *__restrict__ gstack,
-                                                    unsigned n_slots,
-                                                    const uint8_t *__restrict__ diffuse_tex,
-                                                    const float4 *__restrict__ normal_tex,
-                                                    const float4 *__restrict__ world_tex,
-                                                    uint32_t first_frame, uint32_t count,
-                                                    const uint32_t *__restrict__ seeds,
-                                                    float4 *__restrict__ samples, DevCounters *__restrict__ counters,
-                                                    unsigned *__restrict__ work_counter,
-                                                    const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
-                                                    uint32_t chunk, Tuning tune, TopLevels top)
+// One wave's share of k_trace_persistent (below), after the workgroup has filled its LDS.  XW (trees in LDS only): this
+// wave keeps its per-level stack entries in global memory (`xst`: this lane's column of `levels` rows of 64 floats), as in
+// dual_paths: the waves that the LDS beside the tree has no stack room for.
+template <bool COUNT, bool LDSN, bool NEAR, bool PAIR, bool GEN, bool XW>
+__device__ __forceinline__ void persistent_paths(const SceneView &sc, const TriIsect *__restrict__ tri_sorted, const int levels,
+                                                 uint2 *__restrict__ gstack,
+                                                 const unsigned n_slots,
+                                                 const uint8_t *__restrict__ diffuse_tex,
+                                                 const float4 *__restrict__ normal_tex,
+                                                 const float4 *__restrict__ world_tex,
+                                                 const uint32_t first_frame, const uint32_t count,
+                                                 const uint32_t *__restrict__ seeds,
+                                                 float4 *__restrict__ samples, DevCounters *__restrict__ counters,
+                                                 unsigned *__restrict__ work_counter,
+                                                 const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
+                                                 const uint32_t chunk, const Tuning &tune, const TopLevels &top,
+                                                 const float4 *lds_nodes, const float4 *lds_mats, const float4 *lds_matq, const int *lds_off,
+                                                 float *stack, const int nthreads, float *__restrict__ xst)
 {
-    // LDS: node records (3 float4 each; LDSN: all of them, else the levels top.k0 and above of an index-keyed tree), the
-    // 16 materials (3 float4 each), their quotient records (1 float4 each), the level offsets of the top part, then the
-    // per-lane stacks
-    extern __shared__ __attribute__((aligned(16))) float4 lds_nodes[];
     const int n = sc.n;
-    const int nthreads = blockDim.x;
-    const bool TOP = !LDSN && !GEN && !PAIR;       // (with child lines the extra branch cost 18 % at 100 M triangles)
-    float4 *lds_mats = lds_nodes + (LDSN ? 3 * n : (TOP ? 3 * top.nodes : 0));
-    float4 *lds_matq = lds_mats + 3 * MAT_SLOTS;
-    int *lds_off = reinterpret_cast<int *>(lds_matq + MAT_SLOTS);
-    float *stack = reinterpret_cast<float *>(lds_matq + MAT_SLOTS + (TOP ? 9 : 0)) + threadIdx.x;   // level L at stack[(L-1) * nthreads]
-    if (LDSN) {
-        for (int i = threadIdx.x; i < 3 * n; i += nthreads) {
-            const int node = i / 3, part = i - 3 * node;
-            lds_nodes[i] = reinterpret_cast<const float4 *>(&sc.wide[node])[part];
-        }
-    }
-    if (TOP) {
-        if (threadIdx.x < 33) lds_off[threadIdx.x] = top.off[threadIdx.x];
-        for (int i = threadIdx.x; i < top.nodes; i += nthreads) {
-            // compact index -> (level, block) -> node id: a left child is named by its last key, others by their first
-            int k = levels;
-            while (k > top.k0 && i >= top.off[k - 1]) k--;
-            const long long b = i - top.off[k];
-            const int id = ((b & 1) == 0 && ((b + 1) << k) <= (long long)n) ? (int)(((b + 1) << k) - 1) : (int)(b << k);
-            const float4 *src = reinterpret_cast<const float4 *>(&sc.wide[id]);
-            lds_nodes[3 * i] = src[0]; lds_nodes[3 * i + 1] = src[1]; lds_nodes[3 * i + 2] = src[2];
-        }
-    }
-    if (threadIdx.x < 3 * MAT_SLOTS)        // the device copy of the constants ends with the zero material
-        lds_mats[threadIdx.x] = reinterpret_cast<const float4 *>(sc.cb->mats)[threadIdx.x];
-    if (threadIdx.x < MAT_SLOTS) {
-        const float4 *mp = reinterpret_cast<const float4 *>(sc.cb->mats) + 3 * threadIdx.x;
-        lds_matq[threadIdx.x] = material_quotients(mp[0], mp[1], mp[2]);
-    }
-    __syncthreads();
-
+    const bool TOP = !LDSN && !GEN && !PAIR;
     const int REFILL_T = tune.refill_t, LEAF_T = tune.leaf_t, ITR_LIMIT = tune.itr_limit;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -771,7 +741,8 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                         // visited first (ties: left, the reference's order); the other waits with ITS distance
                         const bool right_first = hl && hr && tr < tl;
                         if (hl && hr) {
-                            stack[__umul24((unsigned)(k - 1), (unsigned)nthreads)] = right_first ? tl : tr;
+                            if (XW) xst[(k - 1) * 64] = right_first ? tl : tr;
+                            else stack[__umul24((unsigned)(k - 1), (unsigned)nthreads)] = right_first ? tl : tr;
                             pending |= 1u << k;
                             if (right_first) pend_left |= 1u << k;
                         }
@@ -780,7 +751,11 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                         cur_id = go_left ? sr - 1 : sr;
                         cur_s = go_left ? cur_s : sr;
                     } else {
-                        if (hl && hr) { stack[__umul24((unsigned)(k - 1), (unsigned)nthreads)] = tr; pending |= 1u << k; }
+                        if (hl && hr) {
+                            if (XW) xst[(k - 1) * 64] = tr;
+                            else stack[__umul24((unsigned)(k - 1), (unsigned)nthreads)] = tr;
+                            pending |= 1u << k;
+                        }
                         cur_k = hl ? k - 1 : (hr ? kr : K_POP);
                         cur_id = hl ? sr - 1 : sr;
                         cur_s = hl ? cur_s : sr;          // after a double miss only the bits above the pending levels matter
@@ -826,7 +801,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                     } else {
                         const int L = __ffs((int)pending) - 1;              // deepest pending ancestor level
                         pending &= pending - 1;
-                        const float t_entry = stack[__umul24((unsigned)(L - 1), (unsigned)nthreads)];
+                        const float t_entry = XW ? xst[(L - 1) * 64] : stack[__umul24((unsigned)(L - 1), (unsigned)nthreads)];
                         const bool left = NEAR && ((pend_left >> L) & 1u);
                         if (NEAR) pend_left &= ~(1u << L);
                         if (t_entry <= current_t) {
@@ -889,6 +864,72 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
     flush_counters(cnt, counters, COUNT);
     if (COUNT && lane == 0) {
         for (int k = 0; k < 10; k++) atomicAdd(&counters->sched[k], sched[k]);
+    }
+}
+
+template <bool COUNT, bool LDSN, bool NEAR, bool PAIR = false, bool GEN = false>
+__global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const TriIsect *__restrict__ tri_sorted, int levels,
+                                                    uint2 *__restrict__ gstack,
+                                                    unsigned n_slots,
+                                                    const uint8_t *__restrict__ diffuse_tex,
+                                                    const float4 *__restrict__ normal_tex,
+                                                    const float4 *__restrict__ world_tex,
+                                                    uint32_t first_frame, uint32_t count,
+                                                    const uint32_t *__restrict__ seeds,
+                                                    float4 *__restrict__ samples, DevCounters *__restrict__ counters,
+                                                    unsigned *__restrict__ work_counter,
+                                                    const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
+                                                    uint32_t chunk, Tuning tune, TopLevels top, int lds_threads, float *__restrict__ xstack)
+{
+    // LDS: node records (3 float4 each; LDSN: all of them, else the levels top.k0 and above of an index-keyed tree), the
+    // 16 materials (3 float4 each), their quotient records (1 float4 each), the level offsets of the top part, then the
+    // per-lane stacks
+    extern __shared__ __attribute__((aligned(16))) float4 lds_nodes[];
+    const int n = sc.n;
+    const int nthreads = blockDim.x;
+    const bool TOP = !LDSN && !GEN && !PAIR;       // (with child lines the extra branch cost 18 % at 100 M triangles)
+    float4 *lds_mats = lds_nodes + (LDSN ? 3 * n : (TOP ? 3 * top.nodes : 0));
+    float4 *lds_matq = lds_mats + 3 * MAT_SLOTS;
+    int *lds_off = reinterpret_cast<int *>(lds_matq + MAT_SLOTS);
+    float *stack = reinterpret_cast<float *>(lds_matq + MAT_SLOTS + (TOP ? 9 : 0)) + threadIdx.x;   // level L at stack[(L-1) * nthreads]
+    if (LDSN) {
+        for (int i = threadIdx.x; i < 3 * n; i += nthreads) {
+            const int node = i / 3, part = i - 3 * node;
+            lds_nodes[i] = reinterpret_cast<const float4 *>(&sc.wide[node])[part];
+        }
+    }
+    if (TOP) {
+        if (threadIdx.x < 33) lds_off[threadIdx.x] = top.off[threadIdx.x];
+        for (int i = threadIdx.x; i < top.nodes; i += nthreads) {
+            // compact index -> (level, block) -> node id: a left child is named by its last key, others by their first
+            int k = levels;
+            while (k > top.k0 && i >= top.off[k - 1]) k--;
+            const long long b = i - top.off[k];
+            const int id = ((b & 1) == 0 && ((b + 1) << k) <= (long long)n) ? (int)(((b + 1) << k) - 1) : (int)(b << k);
+            const float4 *src = reinterpret_cast<const float4 *>(&sc.wide[id]);
+            lds_nodes[3 * i] = src[0]; lds_nodes[3 * i + 1] = src[1]; lds_nodes[3 * i + 2] = src[2];
+        }
+    }
+    if (threadIdx.x < 3 * MAT_SLOTS)        // the device copy of the constants ends with the zero material
+        lds_mats[threadIdx.x] = reinterpret_cast<const float4 *>(sc.cb->mats)[threadIdx.x];
+    if (threadIdx.x < MAT_SLOTS) {
+        const float4 *mp = reinterpret_cast<const float4 *>(sc.cb->mats) + 3 * threadIdx.x;
+        lds_matq[threadIdx.x] = material_quotients(mp[0], mp[1], mp[2]);
+    }
+    __syncthreads();
+
+    // trees in LDS: waves beyond `lds_threads` keep their stack entries in global memory (see k_trace_dual); every other
+    // variant is launched with lds_threads = blockDim.x
+    if (LDSN && !PAIR && !GEN && __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= lds_threads) {
+        const size_t xwave = (size_t)blockIdx.x * ((blockDim.x - lds_threads) >> 6) + ((threadIdx.x - lds_threads) >> 6);
+        persistent_paths<COUNT, LDSN, NEAR, PAIR, GEN, LDSN && !PAIR && !GEN>(
+            sc, tri_sorted, levels, gstack, n_slots, diffuse_tex, normal_tex, world_tex, first_frame, count, seeds, samples, counters,
+            work_counter, order, pixel_work, chunk, tune, top, lds_nodes, lds_mats, lds_matq, lds_off, stack, lds_threads,
+            xstack + xwave * 64 * (size_t)levels + (threadIdx.x & 63));
+    } else {
+        persistent_paths<COUNT, LDSN, NEAR, PAIR, GEN, false>(
+            sc, tri_sorted, levels, gstack, n_slots, diffuse_tex, normal_tex, world_tex, first_frame, count, seeds, samples, counters,
+            work_counter, order, pixel_work, chunk, tune, top, lds_nodes, lds_mats, lds_matq, lds_off, stack, lds_threads, nullptr);
     }
 }
 
@@ -1964,12 +2005,13 @@ static size_t stack_bytes(const pt_context *ctx)
 
 // Largest workgroup (multiple of 64, at most 1024 threads) whose per-level stack fits
 // beside the node records in the CU's 160 KiB of LDS; 0 when the tree does not fit.
-// LDS residency pays while at least eight waves fit beside the tree (measured with the single-path kernel: a 2800-triangle
-// soup breaks even at 8 waves, a 3000-triangle one runs 25 % slower at 5 waves than from global memory at 16).  k_trace_dual,
-// which fills the workgroup up to 1024 threads with waves whose stacks are in global memory, would still gain down to 5
-// LDS waves (scene04 padded to 3000 triangles: 166 ms per 128 frames against 184 ms from global memory; break-even at 4),
-// but short launches run the single-path kernel, so the limit stays.
-constexpr int LDS_TREE_MIN_THREADS = 512;
+// LDS residency pays while the stacks of at least five waves fit beside the tree: the workgroup is filled to 1024 threads with
+// waves whose stacks are in global memory (3 KB per wave, which must stay in the CU's 32 KB L1 beside the triangle records).
+// scene04 padded to n triangles, ms per 128 frames with the tree in LDS / read from global memory at 16 waves: n = 2800 (9 LDS
+// stacks) 157 / 178, 3000 (6) 166 / 184, 3100 (4) 181 / 181, 3250 (2) 235 / 192; one-frame calls 2.41 / 3.18, 2.53 / 3.33,
+// 2.53 / 3.28 ms.  (Without the extra waves the limit was eight waves: a 3000-triangle tree ran 25 % slower at 5 waves than
+// from global memory at 16.)
+static int lds_tree_min_threads(const pt_context *ctx) { return ctx->knobs.extra_wave > 0 ? 320 : 512; }
 
 static int lds_resident_threads(const pt_context *ctx, int *levels_out, size_t *bytes_out)
 {
@@ -2003,7 +2045,7 @@ bool ptk_tree_in_lds(const pt_context *ctx)
 {
     int levels = 0;
     size_t bytes = 0;
-    return !(ctx->build_flags & PT_BUILD_TOPOLOGY_MORTON) && !ctx->knobs.no_lds_tree && lds_resident_threads(ctx, &levels, &bytes) >= LDS_TREE_MIN_THREADS;
+    return !(ctx->build_flags & PT_BUILD_TOPOLOGY_MORTON) && !ctx->knobs.no_lds_tree && lds_resident_threads(ctx, &levels, &bytes) >= lds_tree_min_threads(ctx);
 }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel variant and context (again only
@@ -2037,14 +2079,14 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
     size_t lds_bytes = 0;
     int threads = lds_resident_threads(ctx, &levels, &lds_bytes);
     if (kn.no_lds_tree) threads = 0;
-    if (threads < LDS_TREE_MIN_THREADS) threads = 0;
+    if (threads < lds_tree_min_threads(ctx)) threads = 0;
     if (kn.max_threads) {      // occupancy experiments: fewer waves per CU
         const int cap = (kn.max_threads / 64) * 64;
         if (cap >= 256 && threads > cap) { lds_bytes -= (size_t)levels * 4 * (size_t)(threads - cap); threads = cap; }
     }
     const bool gen = (ctx->build_flags & PT_BUILD_TOPOLOGY_MORTON) != 0;
     if (gen) threads = 0;                           // explicit child ids: the records stay in global memory
-    const bool lds_nodes = threads >= 256;          // else: node records stay in global memory
+    const bool lds_nodes = threads >= 320;          // else: node records stay in global memory
     if (gen) {
         // LDS holds the materials and the first `levels` entries of every lane's (node, distance) stack; a tree higher
         // than that keeps the rest of the stacks in global memory
@@ -2223,6 +2265,12 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             while (frame_lanes_log2 < 8 && (2u << frame_lanes_log2) <= cnt) frame_lanes_log2++;
             hipLaunchKernelGGL(k_path_seeds, dim3((unsigned)ctx->num_cus * 16u), dim3(256), 0, ctx->stream, ctx->W, (unsigned)npix, cnt,
                                seeds, ctx->d_samples, frame_lanes_log2);
+            // A tree in LDS leaves stack room for `threads` lanes; the waves up to 1024 threads (scene04: one, the sixteenth)
+            // run too, with their stack entries in global memory: 115 -> 109 ms per 128 frames of scene04.
+            int xthreads = lds_nodes ? 1024 - threads : 0;
+            if (xthreads > 64 * kn.extra_wave) xthreads = 64 * kn.extra_wave;
+            if (xthreads && !ctx->d_xstack)      // 16 waves x 32 levels x 64 lanes per CU: every case
+                PT_HIP(ctx, hipMalloc((void **)&ctx->d_xstack, (size_t)ctx->num_cus * 16 * 32 * 64 * sizeof(float)));
 #define PT_LAUNCH(SLOT, C, L, N) PT_LAUNCH_(SLOT, C, L, N, false, false)
 #define PT_LAUNCH_G(SLOT, C, N) do { \
             if (gen) { if (use_pair) PT_LAUNCH_(SLOT + 22, C, false, N, true, true); else PT_LAUNCH_(SLOT + 16, C, false, N, false, true); } \
@@ -2230,11 +2278,11 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
 #define PT_LAUNCH_(SLOT, C, L, N, P, G) do { \
             if (int rc_ = ensure_lds_limit(ctx, SLOT, &k_trace_persistent<C, L, N, P, G>, lds_bytes)) return rc_; \
             if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream)); \
-            hipLaunchKernelGGL((k_trace_persistent<C, L, N, P, G>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
+            hipLaunchKernelGGL((k_trace_persistent<C, L, N, P, G>), dim3(ctx->num_cus), dim3(threads + ((L) ? xthreads : 0)), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
                 ctx->d_gstack, n_slots, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, seeds, \
                 ctx->d_samples, ctx->d_counters, ctx->d_work, \
                 order, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, \
-                (uint32_t)chunk, tune, top); } while (0)
+                (uint32_t)chunk, tune, top, threads, ctx->d_xstack); } while (0)
             // slot of the variant in ctx->lds_attr: COUNT, LDSN, NEAR as bits; + 10 with pair lines, + 16 / + 22 for trees with
             // explicit child ids (without / with pair lines); 8, 9: wavefront; 28, 29: the per-ray kernels
             // two paths per lane need items of several frames (the two paths are two frames of one pixel): short launches,
@@ -2242,12 +2290,6 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             if ((lds_nodes || (!gen && !use_pair)) && !near_first && kn.dual && chunk >= (unsigned long long)kn.dual_min_chunk) {
                 // k_trace_dual: slots 30, 31 (tree in LDS), 18, 19 (plain records from global memory)
                 Tuning dt = tune;
-                // A tree in LDS leaves stack room for `threads` lanes; the waves up to 1024 threads (scene04: one, the sixteenth)
-                // run too, with their stack entries in global memory: 115 -> 109 ms per 128 frames of scene04.
-                int xthreads = lds_nodes ? 1024 - threads : 0;
-                if (xthreads > 64 * kn.extra_wave) xthreads = 64 * kn.extra_wave;
-                if (xthreads && !ctx->d_xstack)      // 16 waves x 32 levels x 64 lanes per CU: every case
-                    PT_HIP(ctx, hipMalloc((void **)&ctx->d_xstack, (size_t)ctx->num_cus * 16 * 32 * 64 * sizeof(float)));
                 dt.refill_t = kn.dual_refill_t;
                 dt.leaf_t = kn.dual_leaf_t;
 #define PT_LAUNCH_DUAL(SLOT, C, L) do { \

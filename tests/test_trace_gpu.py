@@ -443,6 +443,35 @@ def test_full_size_frames_bit_exact(gpu_ctx_factory, golden, scene):
     assert ctx.counters()["rays"] == rays
 
 
+@pytest.mark.parametrize("schedule", [ptamd.PT_SCHEDULE_PERSISTENT, "dual"])
+def test_tree_beside_few_lds_stacks_every_wave_busy(gpu_ctx_factory, monkeypatch, schedule):
+    """A 3000-triangle tree leaves LDS room for the stacks of six waves; ten more waves per CU run with their stack entries
+    in global memory.  640x416 pixels give every wave of every CU work, so both kinds of wave, in the one-path and the
+    two-path kernel, are compared with the oracle: the sums of four frames and all counters."""
+    n, W, H = 3000, 640, 416
+    prims = make_soup(n, seed=n)
+    prims["matid"] = np.arange(n) % 4
+    cb = soup_cb(n)
+    ob = orc.build(prims)
+    ctx = _ctx_with_schedule(gpu_ctx_factory, monkeypatch, schedule)
+    ctx.upload_primitives(prims); ctx.set_constants(cb); ctx.build(); ctx.resize(W, H)
+    alb = ptamd.albedo_table([list(cb["mats"][0][m]["kd"][:3]) for m in range(16)])
+    cam = dict(eye=(0.5, 0.5, 2.2), at=(0.5, 0.5, 0.5))
+    ctx.primary_hits(ptamd.default_camera(**cam), alb)
+    sc = orc.OracleScene(prims, ob["tree"], cb)
+    gb = orc.primary(sc, orc.default_camera(**cam), W, H, alb)
+    seeds = ptamd.frame_seeds(5, 0, 4)
+    ctx.set_detailed_counters(True)
+    ctx.trace_frames(0, seeds, ptamd.PT_ACCUM_LINEAR)
+    acc = np.zeros((H, W, 4), np.float32)
+    tot = dict(paths=0, rays=0, node_visits=0, box_tests=0, tri_tests=0)
+    for f in range(4):
+        c = orc.trace_frame_linear(sc, gb, f, seeds[f], acc)
+        tot = {k: tot[k] + c[k] for k in tot}
+    assert np.array_equal(_bits(ctx.linear_sum()), _bits(acc))
+    assert ctx.counters() == tot and tot["rays"] > tot["paths"] // 4
+
+
 @pytest.mark.parametrize("extra_waves", ["16", "0"])
 def test_full_size_two_paths_per_lane_with_and_without_extra_waves(gpu_ctx_factory, golden, monkeypatch, extra_waves):
     """scene04's tree leaves LDS room for the stacks of 15 waves; k_trace_dual runs a sixteenth whose stack entries live in
