@@ -403,14 +403,20 @@ def main():
     if world > 1:
         reduce_via = "torch.distributed.all_reduce"
         if backend == "nccl":
-            ok = 1
-            try:
-                cid = [ptamd.unique_comm_id() if rank == 0 else None]
-                dist.broadcast_object_list(cid, src=0)
-                ctx.comm_init_rank(world, rank, cid[0])
-            except Exception as e:       # noqa: BLE001 -- reported below, every rank takes the same branch
-                print(f"bench.py rank {rank}: pt_comm_init_rank failed: {e}", file=sys.stderr)
-                ok = 0
+            ok = 0
+            cid = [None]
+            if rank == 0:
+                try:
+                    cid[0] = ptamd.unique_comm_id()
+                except Exception as e:   # noqa: BLE001 -- the broadcast below still happens: nobody waits for a rank that gave up
+                    print(f"bench.py rank 0: pt_comm_unique_id failed: {e}", file=sys.stderr)
+            dist.broadcast_object_list(cid, src=0)
+            if cid[0] is not None:
+                try:
+                    ctx.comm_init_rank(world, rank, cid[0])
+                    ok = 1
+                except Exception as e:   # noqa: BLE001 -- reported below, every rank takes the same branch
+                    print(f"bench.py rank {rank}: pt_comm_init_rank failed: {e}", file=sys.stderr)
             flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:

@@ -584,9 +584,10 @@ static int trace_frames(pt_context *ctx, const char *who, uint32_t first_frame, 
     if (int rc = check_trace_ready(ctx, who)) return rc;
     if (!seeds || count < 1) PT_FAIL(ctx, PT_ERR_INVALID, std::string(who) + ": need count >= 1 seeds");
     if (mode != PT_ACCUM_LITERAL && mode != PT_ACCUM_LINEAR) PT_FAIL(ctx, PT_ERR_INVALID, std::string(who) + ": bad mode");
-    // Short whole-image calls on a tree in LDS are overlapped (see PipeSlot): at most 8 frames, persistent schedule
+    // Short whole-image calls are overlapped (see PipeSlot): at most 8 frames, persistent schedule, a tree in LDS or read as
+    // plain records (no child lines or deep stack entries, which a launch may have to create)
     const bool overlapped = ctx->overlap && !ctx->user_stream && !region && count <= 8 && ctx->W * (size_t)ctx->H * count <= ((size_t)1 << 26) &&
-                            ctx->schedule == PT_SCHEDULE_PERSISTENT && ptk_tree_in_lds(ctx);
+                            ctx->schedule == PT_SCHEDULE_PERSISTENT && ptk_short_calls_may_overlap(ctx);
     if (!overlapped) { if (int rc = set_device(ctx)) return rc; }
     else PT_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->h_seeds_cap < count) {

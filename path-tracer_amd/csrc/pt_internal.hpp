@@ -251,5 +251,6 @@ int ptk_export_tree(pt_context *ctx);
 int ptk_primary(pt_context *ctx, const pt_camera *cam, const uint8_t *d_albedo);
 int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int mode, const int *region);
 bool ptk_tree_in_lds(const pt_context *ctx);
+bool ptk_short_calls_may_overlap(const pt_context *ctx);
 int ptk_resolve(pt_context *ctx);
 int ptk_intersect(pt_context *ctx, const float *d_rays8, int n_rays, pt_hit *d_out);

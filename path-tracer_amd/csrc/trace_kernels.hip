@@ -2041,6 +2041,21 @@ static uint32_t frames_per_launch(const pt_context *ctx, uint32_t count, bool wa
     return (uint32_t)(count < cap ? count : cap);
 }
 
+// Plain-record trees in global memory (index-keyed, too small for child lines): like trees in LDS they need no buffer that
+// a launch creates or resizes (child lines, deep stack entries), so short calls on them may overlap on the internal streams.
+static bool uses_child_lines(const pt_context *ctx)
+{
+    const Knobs &kn = ctx->knobs;
+    const size_t pair_max_nodes = kn.pair_max_mib > 0 ? ((size_t)kn.pair_max_mib << 20) / 128 : 0;
+    return (size_t)ctx->n <= pair_max_nodes && (size_t)ctx->n * 64 >= ((size_t)kn.pair_min_mib << 20);
+}
+
+bool ptk_short_calls_may_overlap(const pt_context *ctx)
+{
+    if (ctx->build_flags & PT_BUILD_TOPOLOGY_MORTON) return false;
+    return ptk_tree_in_lds(ctx) || !uses_child_lines(ctx);
+}
+
 bool ptk_tree_in_lds(const pt_context *ctx)
 {
     int levels = 0;
@@ -2116,8 +2131,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
     // at every size that does not fit in LDS (PTAMD_PAIR_MAX_MIB bounds the array; 0 = plain records)
     // ... once the plain records (64 n bytes) approach the size of the L2s (8 x 4 MiB): below about 400 k triangles the
     // records come from the caches anyway and the lines' extra instructions and registers cost 10-30 % (PTAMD_PAIR_MIN_MIB)
-    const size_t pair_max_nodes = kn.pair_max_mib > 0 ? ((size_t)kn.pair_max_mib << 20) / 128 : 0;
-    const bool use_pair = !lds_nodes && (size_t)ctx->n <= pair_max_nodes && (size_t)ctx->n * 64 >= ((size_t)kn.pair_min_mib << 20);
+    const bool use_pair = !lds_nodes && uses_child_lines(ctx);
     // Index-keyed trees that do not fit in LDS as a whole and are read as plain records keep their upper levels in LDS: as
     // many whole levels, from the root down, as fit beside the stacks: 3-9 % (child ids follow from level and block, so
     // the LDS copy needs no id table; together with child lines it measured 1-5 % slower).

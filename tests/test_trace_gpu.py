@@ -620,14 +620,18 @@ def test_trace_timing_reports_one_duration_per_launch(gpu_ctx_factory, golden):
     assert len(ctx.trace_times()) == 0
 
 
-def test_overlapped_short_calls_equal_serial_ones(gpu_ctx_factory, golden):
+@pytest.mark.parametrize("tree", ["lds", "global"])
+def test_overlapped_short_calls_equal_serial_ones(gpu_ctx_factory, golden, monkeypatch, tree):
     """Short trace calls run on two internal streams in turn (pt_set_trace_overlap, the default); the images must be the
     ones of the same calls issued with overlap off, whatever is mixed in between: single frames, a 4-frame call, a
-    long call on the context's stream, a reset of the images, region dispatches, counters and downloads."""
+    long call on the context's stream, a reset of the images, region dispatches, counters and downloads.  With the tree
+    in LDS and read as plain records from global memory (the two kinds of tree whose short calls overlap)."""
     W, H = 192, 144
     g = golden["scene04"]
     seeds = ptamd.frame_seeds(1, 0, 64)
     results = []
+    if tree == "global":
+        monkeypatch.setenv("PTAMD_NO_LDS_TREE", "1")
     for overlap in (True, False):
         ctx = gpu_ctx_factory()
         ctx.set_trace_overlap(overlap)
