@@ -2281,7 +2281,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
                                seeds, ctx->d_samples, frame_lanes_log2);
             // A tree in LDS leaves stack room for `threads` lanes; the waves up to 1024 threads (scene04: one, the sixteenth)
             // run too, with their stack entries in global memory: 115 -> 109 ms per 128 frames of scene04.
-            int xthreads = lds_nodes ? 1024 - threads : 0;
+            int xthreads = (lds_nodes && !kn.max_threads) ? 1024 - threads : 0;       // (PTAMD_MAX_THREADS asks for FEWER waves)
             if (xthreads > 64 * kn.extra_wave) xthreads = 64 * kn.extra_wave;
             if (xthreads && !ctx->d_xstack)      // 16 waves x 32 levels x 64 lanes per CU: every case
                 PT_HIP(ctx, hipMalloc((void **)&ctx->d_xstack, (size_t)ctx->num_cus * 16 * 32 * 64 * sizeof(float)));
