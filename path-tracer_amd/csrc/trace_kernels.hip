@@ -415,8 +415,12 @@ constexpr int EXPANSIONS = PT_EXPANSIONS;      // node expansions per pass of th
 // One wave's share of k_trace_persistent (below), after the workgroup has filled its LDS.  XW (trees in LDS only): this
 // wave keeps its per-level stack entries in global memory (`xst`: this lane's column of `levels` rows of 64 floats), as in
 // dual_paths: the waves that the LDS beside the tree has no stack room for.
+// (The structures arrive BY VALUE, as the kernel itself receives them: handed over by reference, the variant with child
+// lines, which runs at the 128-register limit, got an allocation that waits at the top of every expansion for the refill
+// round's sample stores before reusing their registers -- 17 % slower on the 100 M-triangle soup, where a store sits behind
+// address-translation misses, and invisible at 10 M.)
 template <bool COUNT, bool LDSN, bool NEAR, bool PAIR, bool GEN, bool XW>
-__device__ __forceinline__ void persistent_paths(const SceneView &sc, const TriIsect *__restrict__ tri_sorted, const int levels,
+__device__ __forceinline__ void persistent_paths(const SceneView sc, const TriIsect *__restrict__ tri_sorted, const int levels,
                                                  uint2 *__restrict__ gstack,
                                                  const unsigned n_slots,
                                                  const uint8_t *__restrict__ diffuse_tex,
@@ -427,7 +431,7 @@ __device__ __forceinline__ void persistent_paths(const SceneView &sc, const TriI
                                                  float4 *__restrict__ samples, DevCounters *__restrict__ counters,
                                                  unsigned *__restrict__ work_counter,
                                                  const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
-                                                 const uint32_t chunk, const Tuning &tune, const TopLevels &top,
+                                                 const uint32_t chunk, const Tuning tune, const TopLevels top,
                                                  const float4 *lds_nodes, const float4 *lds_mats, const float4 *lds_matq, const int *lds_off,
                                                  float *stack, const int nthreads, float *__restrict__ xst)
 {
@@ -927,9 +931,11 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
             work_counter, order, pixel_work, chunk, tune, top, lds_nodes, lds_mats, lds_matq, lds_off, stack, lds_threads,
             xstack + xwave * 64 * (size_t)levels + (threadIdx.x & 63));
     } else {
+        // (variants without extra waves: the workgroup's own size, whose range the compiler knows)
         persistent_paths<COUNT, LDSN, NEAR, PAIR, GEN, false>(
             sc, tri_sorted, levels, gstack, n_slots, diffuse_tex, normal_tex, world_tex, first_frame, count, seeds, samples, counters,
-            work_counter, order, pixel_work, chunk, tune, top, lds_nodes, lds_mats, lds_matq, lds_off, stack, lds_threads, nullptr);
+            work_counter, order, pixel_work, chunk, tune, top, lds_nodes, lds_mats, lds_matq, lds_off, stack,
+            (LDSN && !PAIR && !GEN) ? lds_threads : nthreads, nullptr);
     }
 }
 
