@@ -315,6 +315,8 @@ int pt_reset_counters(pt_context *ctx);
  * ones live in global memory; default: as many as fit, 19 at 1024 threads),
  * PTAMD_EXTRA_WAVES (trees in LDS, two-path kernel: most waves per CU that run beyond those whose traversal stacks fit in
  * LDS beside the tree, with their stack entries in global memory; 16 = fill the workgroup to 1024 threads, 0 = none),
+ * PTAMD_FINE_FRAC / PTAMD_FINE_CHUNK (two-path kernel: the last 1/FRAC of a launch's frames is handed out in work items of
+ * CHUNK frames instead of the launch's item length, so that the launch ends on short items: 4 / 8; FRAC 0 = off),
  * PTAMD_SORT_CHAINED=0 (PT_BUILD_MORTON_FULL: a counting pass and a scan before each of the eight radix passes instead of
  * one count of all digits up front and passes that find their offsets by looking back over the tiles before them). */
 

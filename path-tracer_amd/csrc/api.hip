@@ -43,6 +43,8 @@ static void read_knobs(Knobs &k)
     k.shade_t = env_int("PTAMD_SHADE_T", k.shade_t);
     k.dual_leaf_t = env_int("PTAMD_DUAL_LEAF_T", k.dual_leaf_t);
     k.sort_chained = env_int("PTAMD_SORT_CHAINED", k.sort_chained);
+    k.fine_frac = env_int("PTAMD_FINE_FRAC", k.fine_frac);
+    k.fine_chunk = env_int("PTAMD_FINE_CHUNK", k.fine_chunk);
     k.extra_wave = env_int("PTAMD_EXTRA_WAVES", k.extra_wave);
 }
 

@@ -344,7 +344,9 @@ constexpr int MAX_ITR = 5;   // ray_tracing.hlsl:245-247
 // Per lane the order of node visits, tests and random draws is exactly that of
 // the sequential loop, so results do not change.
 // ---------------------------------------------------------------------------
-struct Tuning { int refill_t, leaf_t; int itr_limit; int swap_t, shade_t; };
+// fine_frames: the last frames of a launch that k_trace_dual hands out in items of fine_chunk frames instead of `chunk`
+// (0: none), so that the launch ends on short items
+struct Tuning { int refill_t, leaf_t; int itr_limit; int swap_t, shade_t; int fine_frames, fine_chunk; };
 // The upper levels of a tree that does not fit in LDS as a whole (index-keyed trees: the node at level k, block b has
 // the compact index off[k] + b): levels k0 .. top are read from LDS, the deeper ones from global memory.
 // k0 > top: nothing in LDS.
@@ -982,8 +984,12 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
     const int STARVE_T = tune.refill_t, SHADE_T = tune.shade_t, LEAF_T = tune.leaf_t, ITR_LIMIT = tune.itr_limit, SWAP_T = tune.swap_t;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const unsigned chunks = (count + chunk - 1) / chunk;
-    const unsigned total_items = n_slots * chunks;
+    // items: first every pixel's coarse chunks of the frames [0, coarse_frames), then every pixel's fine chunks of the rest
+    const unsigned coarse_frames = count - (unsigned)tune.fine_frames, fine_chunk = (unsigned)tune.fine_chunk;
+    const unsigned chunks = (coarse_frames + chunk - 1) / chunk;
+    const unsigned fine_chunks = tune.fine_frames ? ((unsigned)tune.fine_frames + fine_chunk - 1) / fine_chunk : 0u;
+    const unsigned coarse_items = n_slots * chunks;
+    const unsigned total_items = coarse_items + n_slots * fine_chunks;
     const float4 *mats = lds_mats;
     const pt_f3 g_pos = pt_mk3(sc.cb->pos.v[0], sc.cb->pos.v[1], sc.cb->pos.v[2]);
     const float root_mn[3] = {sc.root[0], sc.root[1], sc.root[2]}, root_mx[3] = {sc.root[3], sc.root[4], sc.root[5]};
@@ -1073,10 +1079,19 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
                     const unsigned rank = (unsigned)__popcll(wm & lt_mask);
                     const unsigned avail = q_end - q_next;
                     if (want && rank < avail) {
-                        const unsigned item = q_next + rank, slot = item / chunks;
+                        const unsigned item = q_next + rank;
+                        unsigned slot;
+                        if (item < coarse_items) {
+                            slot = item / chunks;
+                            f = (item - slot * chunks) * chunk;
+                            f_end = min(f + chunk, coarse_frames);
+                        } else {
+                            const unsigned j = item - coarse_items;
+                            slot = j / fine_chunks;
+                            f = coarse_frames + (j - slot * fine_chunks) * fine_chunk;
+                            f_end = min(f + fine_chunk, count);
+                        }
                         px = order ? order[slot] : slot;
-                        f = (item - slot * chunks) * chunk;
-                        f_end = min(f + chunk, count);
                         work_start = iterations;
                         const uchar4 dif8 = reinterpret_cast<const uchar4 *>(diffuse_tex)[px];
                         const float4 nrm4 = normal_tex[px];
@@ -2093,7 +2108,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
     SceneView sv;
     if (int rc = make_view(ctx, sv)) return rc;
     const Knobs &kn = ctx->knobs;
-    Tuning tune = {kn.refill_t, kn.leaf_t, ctx->itr_limit, kn.swap_t, kn.shade_t};
+    Tuning tune = {kn.refill_t, kn.leaf_t, ctx->itr_limit, kn.swap_t, kn.shade_t, 0, 0};
     const bool lin = (mode == PT_ACCUM_LINEAR);
     const size_t npix = (size_t)ctx->W * ctx->H;
     int levels = 0;
@@ -2245,7 +2260,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             PathRec *queue[2] = {static_cast<PathRec *>(ctx->d_wf_queue[0]), static_cast<PathRec *>(ctx->d_wf_queue[1])};
             HitRec *hits = static_cast<HitRec *>(ctx->d_wf_hits);
             const dim3 fgrid((unsigned)ctx->num_cus * 8u), sgrid(32, WF_SEGS);
-            Tuning wt = {kn.wf_refill_t, kn.wf_leaf_t, ctx->itr_limit, kn.swap_t, kn.shade_t};
+            Tuning wt = {kn.wf_refill_t, kn.wf_leaf_t, ctx->itr_limit, kn.swap_t, kn.shade_t, 0, 0};
             if (int rc = ensure_lds_limit(ctx, 8, &k_wf_extend<false>, lds_bytes)) return rc;
             if (int rc = ensure_lds_limit(ctx, 9, &k_wf_extend<true>, lds_bytes)) return rc;
             if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream));
@@ -2310,6 +2325,15 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             if ((lds_nodes || (!gen && !use_pair)) && !near_first && kn.dual && chunk >= (unsigned long long)kn.dual_min_chunk) {
                 // k_trace_dual: slots 30, 31 (tree in LDS), 18, 19 (plain records from global memory)
                 Tuning dt = tune;
+                if (kn.fine_frac > 0 && kn.fine_chunk >= 1 && !kn.chunk) {
+                    // the last 1/fine_frac of the launch's frames in short items
+                    unsigned fine = cnt / (unsigned)kn.fine_frac;
+                    fine -= fine % (unsigned)kn.fine_chunk;
+                    if (fine >= (unsigned)kn.fine_chunk && cnt - fine >= chunk && (unsigned)kn.fine_chunk < chunk) {
+                        dt.fine_frames = (int)fine;
+                        dt.fine_chunk = kn.fine_chunk;
+                    }
+                }
                 dt.refill_t = kn.dual_refill_t;
                 dt.leaf_t = kn.dual_leaf_t;
 #define PT_LAUNCH_DUAL(SLOT, C, L) do { \
