@@ -1304,13 +1304,6 @@ int ptk_build(pt_context *ctx, unsigned flags)
     if (int rc = run_build(ctx, b, reinterpret_cast<const uint4 *>(ctx->d_prims), ctx->n, flags, ctx->ev, &ctx->sorted_buf, chained)) return rc;
     ctx->morton_bits = full ? 64 : 32;
     ctx->sort_passes = full ? 8 : 2;
-    if (chained) {
-        // a workgroup of a chained pass that gave up waiting leaves a wrong order behind: the build has failed
-        unsigned gave_up = 0;
-        PT_HIP(ctx, hipMemcpyAsync(&gave_up, ctx->d_digit_total + CH_ERROR_WORD, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (gave_up) PT_FAIL(ctx, PT_ERR_HIP, "pt_build: a sorting workgroup gave up waiting for the tiles before it (PTAMD_SORT_CHAINED=0 selects the two-read passes)");
-    }
     ctx->boxes_valid = !build_keeps_centres_only(flags);
     ctx->tree_height = 0;
     if (flags & PT_BUILD_TOPOLOGY_MORTON) {
@@ -1331,6 +1324,14 @@ int ptk_build(pt_context *ctx, unsigned flags)
     if (int rc = ptk_root_box(ctx)) return rc;
     ctx->trace_records = (flags & PT_BUILD_TREE_ONLY) == 0;
     PT_HIP(ctx, hipEventRecord(ctx->ev[PT_STAGE_PACK + 1], ctx->stream));
+    if (chained) {
+        // a workgroup of a chained pass that gave up waiting leaves a wrong order behind: the build has failed
+        // (read back after the last stage event, so that the host's round trip is in no stage time)
+        unsigned gave_up = 0;
+        PT_HIP(ctx, hipMemcpyAsync(&gave_up, ctx->d_digit_total + CH_ERROR_WORD, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (gave_up) PT_FAIL(ctx, PT_ERR_HIP, "pt_build: a sorting workgroup gave up waiting for the tiles before it (PTAMD_SORT_CHAINED=0 selects the two-read passes)");
+    }
     return PT_OK;
 }
 
