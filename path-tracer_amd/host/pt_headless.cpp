@@ -18,6 +18,9 @@ int main(int argc, char **argv)
     const int frames = argc > 4 ? std::atoi(argv[4]) : 100;
     const char *out = argc > 5 ? argv[5] : "snapshot.bmp";
     const char *snapshot_dir = argc > 6 ? argv[6] : nullptr;
+    // nobody looks at the image between frames here: queue four stratification cycles per launch (the class's default of 32
+    // suits an interactive caller); snapshots and the final image flush the queue
+    ray_tracer.frames_per_launch = 128;
     ray_tracer.loadScene(argv[1]);
     ray_tracer.loadShaders();
     ray_tracer.createBuffers();
