@@ -32,6 +32,12 @@ public:
     int output_tex_index = -1, output_unorm_tex_index = -1;
     int gbuffer_tex_index = -1, gbuffer_srv_index = -1, gbuffer2_tex_index = -1, gbuffer2_srv_index = -1;
     int gbuffer3_tex_index = -1, gbuffer3_srv_index = -1;
+    int gbuffer4_tex_index = -1, gbuffer4_srv_index = -1;
+    int halton_tex_index = -1, halton_tex_srv_index = -1;
+    // the shader file names of the reference (LPCWSTR there); nothing is compiled at run time here
+    const wchar_t *const RADIX_SHADER_NAME = L"radix_build_cs.hlsl";
+    const wchar_t *const BVH_SHADER_NAME = L"bvh_build_cs.hlsl";
+    const wchar_t *const RAY_SHADER_NAME = L"ray_tracing.hlsl";
 
     Scene scene;
     Bound bb_;
@@ -45,7 +51,10 @@ public:
     void loadScene(const char *filename);
     void loadShaders();                                 // kernels are compiled ahead of time: no-op
     void createBuffers();                               // reference: ray_tracer.cpp:91-172
-    void run();                                         // reference: ray_tracer.cpp:174-186 (no D3D context argument)
+    void run();                                         // reference: ray_tracer.cpp:174-186
+    // the reference's signature, run(ID3D11DeviceContext *): the pointer is kept as the reference keeps it and never used
+    void *pd3dImmediateContext_ = nullptr;
+    void run(void *pd3dImmediateContext) { pd3dImmediateContext_ = pd3dImmediateContext; run(); }
     void resize(int width, int height);                 // reference: ray_tracer.cpp:188-261
     void buildRadixTree();                              // reference: ray_tracer.cpp:263-269
     void buildBVH();                                    // reference: ray_tracer.cpp:271-279 (fused into the build)
