@@ -150,12 +150,8 @@ __device__ __forceinline__ uint64_t spread3(uint64_t v)
 }
 
 template <typename K, bool MIDS>
-__global__ __launch_bounds__(256) void k_morton(const BoxRec *__restrict__ boxes, int n,
-                                                const unsigned *__restrict__ bbox_enc, float cells,
-                                                K *__restrict__ codes)
+__device__ __forceinline__ K morton_code(const BoxRec *__restrict__ boxes, long long i, const unsigned *__restrict__ bbox_enc, float cells)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
     float midx, midy, midz;
     if (MIDS) {
         const float *src = reinterpret_cast<const float *>(boxes) + 3 * (size_t)i;
@@ -177,7 +173,41 @@ __global__ __launch_bounds__(256) void k_morton(const BoxRec *__restrict__ boxes
     uint64_t a = (qa != qa) ? 0 : (uint64_t)qa;
     uint64_t b = (qb != qb) ? 0 : (uint64_t)qb;
     uint64_t c = (qc != qc) ? 0 : (uint64_t)qc;
-    codes[i] = (K)((spread3(a) << 2) | (spread3(b) << 1) | spread3(c));
+    return (K)((spread3(a) << 2) | (spread3(b) << 1) | spread3(c));
+}
+
+template <typename K, bool MIDS>
+__global__ __launch_bounds__(256) void k_morton(const BoxRec *__restrict__ boxes, int n,
+                                                const unsigned *__restrict__ bbox_enc, float cells,
+                                                K *__restrict__ codes)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) codes[i] = morton_code<K, MIDS>(boxes, i, bbox_enc, cells);
+}
+
+// The same codes, one sorting tile (PT_SORT_TILE keys) per workgroup, together with the tile's counts of the lowest digit:
+// what k_sort_hist would count for the first radix pass by reading the codes again (block_hist is digit-major, as there).
+template <typename K, bool MIDS>
+__global__ __launch_bounds__(PT_SORT_THREADS) void k_morton_hist(const BoxRec *__restrict__ boxes, int n,
+                                                                 const unsigned *__restrict__ bbox_enc, float cells,
+                                                                 K *__restrict__ codes, uint32_t *__restrict__ block_hist, int nblocks)
+{
+    __shared__ uint32_t h[256];
+    const int t = threadIdx.x;
+    h[t] = 0;
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * PT_SORT_TILE;
+#pragma unroll 4
+    for (int r = 0; r < PT_SORT_ITEMS; r++) {
+        const long long i = base + r * PT_SORT_THREADS + t;
+        if (i < n) {
+            const K code = morton_code<K, MIDS>(boxes, i, bbox_enc, cells);
+            codes[i] = code;
+            atomicAdd(&h[(unsigned)code & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    block_hist[(size_t)t * nblocks + blockIdx.x] = h[t];
 }
 
 // ---------------------------------------------------------------------------
@@ -1093,7 +1123,7 @@ inline int bit_length(unsigned v) { return v ? 32 - __builtin_clz(v) : 0; }
 // (into the kbuf of the same index).
 template <typename K>
 static int radix_sort_passes(hipStream_t st, const K *keys, int n, int passes, K *const kbuf[2], uint32_t *const vbuf[2],
-                             uint32_t *block_hist, uint32_t *digit_total, bool keys_last = false)
+                             uint32_t *block_hist, uint32_t *digit_total, bool keys_last = false, bool first_counted = false)
 {
     const int nblocks = (n + PT_SORT_TILE - 1) / PT_SORT_TILE;
     const K *kin = keys;
@@ -1103,7 +1133,8 @@ static int radix_sort_passes(hipStream_t st, const K *keys, int n, int passes, K
         const int shift = 8 * p;
         uint32_t *dtot = digit_total + 256 * p;
         const bool first = (p == 0), last = (p == passes - 1) && !keys_last;
-        hipLaunchKernelGGL(k_sort_hist<K>, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, n, shift, block_hist, nblocks);
+        if (!(first && first_counted))      // (k_morton_hist has counted the first pass's digits already)
+            hipLaunchKernelGGL(k_sort_hist<K>, dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, n, shift, block_hist, nblocks);
         hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, st, block_hist, dtot, nblocks);
 #define PT_SCATTER(I, KO) hipLaunchKernelGGL((k_sort_scatter<K, I, KO, false>), dim3(nblocks), dim3(PT_SORT_THREADS), 0, st, kin, vin, \
                                              kbuf[out], vbuf[out], n, shift, block_hist, dtot, nblocks, nullptr, nullptr, nullptr)
@@ -1197,9 +1228,13 @@ static int run_build(pt_context *ctx, const BuildBufs &b, const uint4 *prims16, 
     const float cells = full ? 2097151.0f : (float)PT_MORTON_CODE_LENGTH_EACH;
     // the reference's codes have 15 bits: 32-bit keys halve the sort's key traffic
 #define PT_MORTON(K, M) hipLaunchKernelGGL((k_morton<K, M>), dim3(grid_n), dim3(256), 0, st, b.boxes, n, b.bbox_enc, cells, static_cast<K *>(b.morton))
+    // the reference's codes: the kernel also counts the lowest digit per sorting tile, so the first radix pass starts at its scan
+#define PT_MORTON_HIST(M) hipLaunchKernelGGL((k_morton_hist<uint32_t, M>), dim3((n + PT_SORT_TILE - 1) / PT_SORT_TILE), dim3(PT_SORT_THREADS), 0, st, \
+                                             b.boxes, n, b.bbox_enc, cells, static_cast<uint32_t *>(b.morton), b.block_hist, (n + PT_SORT_TILE - 1) / PT_SORT_TILE)
     if (full) { if (mids) PT_MORTON(uint64_t, true); else PT_MORTON(uint64_t, false); }
-    else      { if (mids) PT_MORTON(uint32_t, true); else PT_MORTON(uint32_t, false); }
+    else      { if (mids) PT_MORTON_HIST(true); else PT_MORTON_HIST(false); }
 #undef PT_MORTON
+#undef PT_MORTON_HIST
     if (ev) PT_HIP(ctx, hipEventRecord(ev[PT_STAGE_MORTON + 1], st));
 
     // The reference quantises each axis to 0..21 (5 bits), so its codes occupy
@@ -1220,7 +1255,7 @@ static int run_build(pt_context *ctx, const BuildBufs &b, const uint4 *prims16, 
     } else {
         uint32_t *const kb[2] = {static_cast<uint32_t *>(b.keys[0]), static_cast<uint32_t *>(b.keys[1])};
         *sorted_buf = radix_sort_passes<uint32_t>(st, static_cast<const uint32_t *>(b.morton), n, passes, kb, b.vals,
-                                                  b.block_hist, b.digit_total, by_codes);
+                                                  b.block_hist, b.digit_total, by_codes, true);
     }
     if (ev) PT_HIP(ctx, hipEventRecord(ev[PT_STAGE_SORT + 1], st));
 
