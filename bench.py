@@ -53,8 +53,9 @@ BUILD_BYTES_TREE = 376
 BUILD_BYTES_DEFAULT = 376 + 96
 # bytes each stage's kernels request per triangle (what this implementation reads + writes, by design)
 STAGE_BYTES = {
-    "tree_only": {"bounds": 80 + 32, "morton": 32 + 4, "sort": (4 + 4 + 8) + (4 + 8 + 4), "refit": 4 + 32 + 64},
-    "default": {"bounds": 80 + 12, "morton": 12 + 4, "sort": (4 + 4 + 8) + (4 + 8 + 4), "refit": 4 + 80 + 64 + 96},
+    # (sort: the first pass's digits are counted by the Morton kernel: scatter 4 r + 8 w; second pass count 4 r, scatter 8 r + 4 w)
+    "tree_only": {"bounds": 80 + 32, "morton": 32 + 4, "sort": (4 + 8) + (4 + 8 + 4), "refit": 4 + 32 + 64},
+    "default": {"bounds": 80 + 12, "morton": 12 + 4, "sort": (4 + 8) + (4 + 8 + 4), "refit": 4 + 80 + 64 + 96},
 }
 PROFILE_TRACE = os.path.join(ROOT, "profiles", "r02_trace_pmc.json")
 PROFILE_BUILD = os.path.join(ROOT, "profiles", "r02_build_pmc.json")
@@ -176,7 +177,7 @@ def bench_build(ctx_factory, n, reps, on_device, copy_gbs):
     prof = load_profile(PROFILE_BUILD) if n == 10_000_000 else None
     traffic = None
     if prof and prof["_current"]:
-        per_build = {"k_bounds": 1, "k_bbox_reduce": 1, "k_morton": 1, "k_sort_hist": 2, "k_sort_scan": 2,
+        per_build = {"k_bounds": 1, "k_bbox_reduce": 1, "k_morton_hist": 1, "k_sort_hist": 1, "k_sort_scan": 2,
                      "k_sort_scatter": 2, "k_refit_low<pack>": 1, "k_refit_upper": 2}
         try:
             traffic = sum(prof[k]["hbm_bytes_per_launch"] * c for k, c in per_build.items())
