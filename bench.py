@@ -21,6 +21,9 @@ reference's index-keyed tree), nearest child first (--near-first 0: the referenc
 (NON-PARITY options, see include/ptamd.h).
 One STEP = one launch of 2 frames.  Node records are read from global memory: this one is bound by HBM.
 
+`python bench.py --gpus N` with N > 1 and no launcher (WORLD_SIZE unset) starts its own N ranks through
+torch.distributed.run before anything touches a GPU; under a launcher whose WORLD_SIZE differs from --gpus it refuses.
+
 value = BVH traversals (`intersect()` calls, counted by the kernel) of all ranks / wall time.
 """
 import argparse
@@ -295,6 +298,34 @@ def trace_roofline_scene(kern_avg_ms, rays_per_launch, bytes_per_ray, launches_p
     return out
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` started as ONE process: start the N ranks (one per GPU) as a child
+    `torch.distributed.run` job with this same command line, pass rank 0's JSON line through, and return the
+    job's exit code.  The parent makes no GPU call (torch and the library are not even imported yet)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PTAMD_BENCH_LAUNCHED_BY=str(os.getpid()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: --gpus {n} without WORLD_SIZE: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    lines = 0
+    for line in child.stdout:
+        if line.startswith("{"):
+            lines += 1
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = child.wait()
+    if rc == 0 and lines != 1:
+        print(f"bench.py: the {n}-rank job printed {lines} JSON lines, expected exactly one", file=sys.stderr)
+        return 3
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -317,6 +348,15 @@ def main():
     ap.add_argument("--no-build", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        # never measure another number of GPUs than the one asked for
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}: refusing to run", file=sys.stderr)
+        sys.exit(2)
 
     # a hang (a rank that never arrives at a collective) ends with every thread's stack on stderr instead of
     # holding the GPU until somebody else's time limit
@@ -342,10 +382,6 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if args.gpus != world:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        args.gpus = world
     torch.cuda.set_device(local_rank)
     stream = torch.cuda.current_stream()
     soup_mode = args.config == "soup100m"
@@ -402,6 +438,7 @@ def main():
     # travels over torch.distributed; if any rank cannot create its communicator all ranks agree to fall back
     # to torch.distributed.all_reduce (the same RCCL), and the JSON line says which one ran.
     reduce_via = "none (one GPU)"
+    rccl_ranks = 0          # ranks of the communicator pt_reduce_linear_sum uses, as ncclCommCount states them
     if world > 1:
         reduce_via = "torch.distributed.all_reduce"
         if backend == "nccl":
@@ -423,6 +460,16 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
                 reduce_via = "pt_reduce_linear_sum (ncclAllReduce through the C ABI)"
+                rccl_ranks = ctx.comm_count()
+                if rccl_ranks != world:
+                    print(f"bench.py rank {rank}: the RCCL communicator spans {rccl_ranks} ranks, {world} were launched", file=sys.stderr)
+                    sys.exit(4)
+            elif rank == 0:
+                print("bench.py: WARNING: no RCCL communicator through the C ABI on at least one rank (see above); the sums are "
+                      "merged by torch.distributed.all_reduce instead -- `reduce_fallback` is true in the JSON line", file=sys.stderr, flush=True)
+        elif rank == 0:
+            print(f"bench.py: WARNING: backend {backend} (rehearsal): the sums are merged by torch.distributed.all_reduce, not by "
+                  "pt_reduce_linear_sum", file=sys.stderr, flush=True)
 
     def reduce():
         if world == 1:
@@ -548,6 +595,8 @@ def main():
             "value": rays / dt / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
+            "rccl_ranks": rccl_ranks,
+            "reduce_fallback": world > 1 and not reduce_via.startswith("pt_reduce"),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,

@@ -219,11 +219,14 @@ int pt_resolve(pt_context *ctx);
  * calls; a process that already holds one (torch.distributed) shares it.
  * pt_comm_unique_id: rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks
  * by any means; pt_comm_init_rank (collective: every rank calls it) is ncclCommInitRank on the
- * context's device; pt_comm_destroy releases it (pt_destroy does too). */
+ * context's device; pt_comm_destroy releases it (pt_destroy does too); pt_comm_count reports the
+ * number of ranks of the context's communicator as RCCL itself states it (ncclCommCount; 0 when the
+ * context has none), so a harness can check that the merge really spans the ranks it launched. */
 typedef struct pt_comm_id { char bytes[128]; } pt_comm_id;
 int pt_comm_unique_id(pt_comm_id *out);                /* errors: pt_last_error(NULL) */
 int pt_comm_init_rank(pt_context *ctx, int n_ranks, int rank, const pt_comm_id *id);
 int pt_comm_destroy(pt_context *ctx);
+int pt_comm_count(pt_context *ctx, int *n_ranks);
 int pt_reduce_linear_sum(pt_context *ctx, void *nccl_comm);
 
 /* outputs: `output` RGBA32F (textures_[output_tex_index]) and `output_u` RGBA8

@@ -13,39 +13,43 @@
 
 static std::string g_create_error;
 
-static int env_int(const char *name, int fallback)
+// an environment knob as an integer, clamped to the range its users are written for
+static int env_int(const char *name, int fallback, int lo, int hi)
 {
     const char *e = getenv(name);
-    return (e && *e) ? atoi(e) : fallback;
+    if (!e || !*e) return fallback;
+    const long v = strtol(e, nullptr, 10);
+    return v < lo ? lo : (v > hi ? hi : (int)v);
 }
 
 // PTAMD_* experiment knobs: read here, once per context, never on the launch path
 static void read_knobs(Knobs &k)
 {
-    k.refill_t = env_int("PTAMD_REFILL_T", k.refill_t);
-    k.leaf_t = env_int("PTAMD_LEAF_T", k.leaf_t);
-    k.wf_refill_t = env_int("PTAMD_WF_REFILL_T", k.wf_refill_t);
-    k.wf_leaf_t = env_int("PTAMD_WF_LEAF_T", k.wf_leaf_t);
-    k.samples_gib = env_int("PTAMD_SAMPLES_GIB", 0);
-    k.no_lds_tree = env_int("PTAMD_NO_LDS_TREE", 0);
-    k.max_threads = env_int("PTAMD_MAX_THREADS", 0);
-    k.no_order = env_int("PTAMD_NO_ORDER", 0);
-    k.chunk = env_int("PTAMD_CHUNK", 0);
-    k.print_sched = env_int("PTAMD_PRINT_SCHED", 0);
-    k.pair_max_mib = env_int("PTAMD_PAIR_MAX_MIB", k.pair_max_mib);
-    k.pair_min_mib = env_int("PTAMD_PAIR_MIN_MIB", k.pair_min_mib);
-    k.gen_lds_entries = env_int("PTAMD_GEN_LDS_ENTRIES", 0);
-    k.no_top_levels = env_int("PTAMD_NO_TOP_LEVELS", 0);
-    k.dual = env_int("PTAMD_DUAL", k.dual);
-    k.dual_min_chunk = env_int("PTAMD_DUAL_MIN_CHUNK", k.dual_min_chunk);
-    k.dual_refill_t = env_int("PTAMD_DUAL_REFILL_T", k.dual_refill_t);
-    k.swap_t = env_int("PTAMD_SWAP_T", k.swap_t);
-    k.shade_t = env_int("PTAMD_SHADE_T", k.shade_t);
-    k.dual_leaf_t = env_int("PTAMD_DUAL_LEAF_T", k.dual_leaf_t);
-    k.sort_chained = env_int("PTAMD_SORT_CHAINED", k.sort_chained);
-    k.fine_frac = env_int("PTAMD_FINE_FRAC", k.fine_frac);
-    k.fine_chunk = env_int("PTAMD_FINE_CHUNK", k.fine_chunk);
-    k.extra_wave = env_int("PTAMD_EXTRA_WAVES", k.extra_wave);
+    // wave-vote thresholds count lanes of one wave
+    k.refill_t = env_int("PTAMD_REFILL_T", k.refill_t, 1, 64);
+    k.leaf_t = env_int("PTAMD_LEAF_T", k.leaf_t, 1, 64);
+    k.wf_refill_t = env_int("PTAMD_WF_REFILL_T", k.wf_refill_t, 1, 64);
+    k.wf_leaf_t = env_int("PTAMD_WF_LEAF_T", k.wf_leaf_t, 1, 64);
+    k.samples_gib = env_int("PTAMD_SAMPLES_GIB", 0, 0, 256);
+    k.no_lds_tree = env_int("PTAMD_NO_LDS_TREE", 0, 0, 1);
+    k.max_threads = env_int("PTAMD_MAX_THREADS", 0, 0, 1024);
+    k.no_order = env_int("PTAMD_NO_ORDER", 0, 0, 1);
+    k.chunk = env_int("PTAMD_CHUNK", 0, 0, 1 << 20);
+    k.print_sched = env_int("PTAMD_PRINT_SCHED", 0, 0, 1);
+    k.pair_max_mib = env_int("PTAMD_PAIR_MAX_MIB", k.pair_max_mib, 0, 1 << 20);
+    k.pair_min_mib = env_int("PTAMD_PAIR_MIN_MIB", k.pair_min_mib, 0, 1 << 20);
+    k.gen_lds_entries = env_int("PTAMD_GEN_LDS_ENTRIES", 0, 0, PT_MAX_TREE_HEIGHT);
+    k.no_top_levels = env_int("PTAMD_NO_TOP_LEVELS", 0, 0, 1);
+    k.dual = env_int("PTAMD_DUAL", k.dual, 0, 1);
+    k.dual_min_chunk = env_int("PTAMD_DUAL_MIN_CHUNK", k.dual_min_chunk, 1, 1 << 20);
+    k.dual_refill_t = env_int("PTAMD_DUAL_REFILL_T", k.dual_refill_t, 1, 64);
+    k.swap_t = env_int("PTAMD_SWAP_T", k.swap_t, 1, 64);
+    k.shade_t = env_int("PTAMD_SHADE_T", k.shade_t, 1, 64);
+    k.dual_leaf_t = env_int("PTAMD_DUAL_LEAF_T", k.dual_leaf_t, 1, 64);
+    k.sort_chained = env_int("PTAMD_SORT_CHAINED", k.sort_chained, 0, 1);
+    k.fine_frac = env_int("PTAMD_FINE_FRAC", k.fine_frac, 0, 1 << 20);
+    k.fine_chunk = env_int("PTAMD_FINE_CHUNK", k.fine_chunk, 0, 1 << 20);
+    k.extra_wave = env_int("PTAMD_EXTRA_WAVES", k.extra_wave, 0, 16);      // a workgroup has at most 16 waves
 }
 
 static int bit_length_u(unsigned v) { return v ? 32 - __builtin_clz(v) : 0; }
@@ -842,6 +846,7 @@ struct RcclApi {
     int (*GetUniqueId)(void *id) = nullptr;                                   // ncclGetUniqueId(ncclUniqueId *)
     int (*CommInitRank)(void **comm, int nranks, pt_comm_id id, int rank) = nullptr;   // ncclUniqueId is 128 bytes, by value
     int (*CommDestroy)(void *comm) = nullptr;
+    int (*CommCount)(void *comm, int *count) = nullptr;
     int (*AllReduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t st) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     std::string err;
@@ -860,10 +865,11 @@ bool rccl_load()
     g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(dlsym(h, "ncclCommCount"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
     auto ar = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.GetErrorString || !ar) {
-        g_rccl.err = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce";
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.CommCount || !g_rccl.GetErrorString || !ar) {
+        g_rccl.err = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclCommCount / ncclAllReduce";
         return false;
     }
     g_rccl.AllReduce = ar;
@@ -904,6 +910,16 @@ int pt_comm_destroy(pt_context *ctx)
     const int r = g_rccl.CommDestroy(ctx->rccl_comm);
     ctx->rccl_comm = nullptr;
     if (r != 0) PT_FAIL(ctx, PT_ERR_HIP, std::string("ncclCommDestroy: ") + g_rccl.GetErrorString(r));
+    return PT_OK;
+}
+
+int pt_comm_count(pt_context *ctx, int *n_ranks)
+{
+    if (!ctx || !n_ranks) return PT_ERR_INVALID;
+    *n_ranks = 0;
+    if (!ctx->rccl_comm) return PT_OK;
+    const int r = g_rccl.CommCount(ctx->rccl_comm, n_ranks);
+    if (r != 0) PT_FAIL(ctx, PT_ERR_HIP, std::string("ncclCommCount: ") + g_rccl.GetErrorString(r));
     return PT_OK;
 }
 

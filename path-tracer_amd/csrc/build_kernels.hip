@@ -1432,7 +1432,7 @@ extern "C" int pt_build_tree_noalloc(pt_context *ctx, const void *dev_prims, int
     b.bbox_partial = reinterpret_cast<float *>(take(6 * (((size_t)n + 255) / 256) * sizeof(float)));
     b.bbox_enc = reinterpret_cast<unsigned *>(take(64));
     b.block_hist = reinterpret_cast<uint32_t *>(take(256 * nblocks * sizeof(uint32_t)));
-    b.digit_total = reinterpret_cast<uint32_t *>(take(8 * 256 * sizeof(uint32_t)));
+    b.digit_total = reinterpret_cast<uint32_t *>(take((8 * 256 + 512) * sizeof(uint32_t)));   // + the spare words every run_build caller provides
     b.chunk = reinterpret_cast<ChunkBox *>(take((nchunks + (nchunks + 2047) / 2048 + 1) * sizeof(ChunkBox)));
     if ((size_t)(p - ctx->d_scratch) > (size_t)PT_NOALLOC_SCRATCH_BYTES)
         PT_FAIL(ctx, PT_ERR_UNSUPPORTED, "pt_build_tree_noalloc: scratch array too small for n");
@@ -1461,7 +1461,7 @@ constexpr size_t r256(size_t b) { return (b + 255) & ~(size_t)255; }
 constexpr size_t noalloc_need(size_t n)
 {
     return r256(n * 32) + r256(n * 64) + 3 * r256(n * 4) + r256(6 * ((n + 255) / 256) * 4) + 256 +
-           r256(256 * ((n + PT_SORT_TILE - 1) / PT_SORT_TILE) * 4) + r256(8 * 256 * 4) +
+           r256(256 * ((n + PT_SORT_TILE - 1) / PT_SORT_TILE) * 4) + r256((8 * 256 + 512) * 4) +
            r256((((n + 1 + 1023) / 1024) + ((n + 1 + 1023) / 1024 + 2047) / 2048 + 1) * sizeof(ChunkBox));
 }
 static_assert(noalloc_need(PT_NOALLOC_MAX_PRIMS) <= PT_NOALLOC_SCRATCH_BYTES, "scratch array too small for PT_NOALLOC_MAX_PRIMS");

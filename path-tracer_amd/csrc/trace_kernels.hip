@@ -2304,8 +2304,13 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             // run too, with their stack entries in global memory: 115 -> 109 ms per 128 frames of scene04.
             int xthreads = (lds_nodes && !kn.max_threads) ? 1024 - threads : 0;       // (PTAMD_MAX_THREADS asks for FEWER waves)
             if (xthreads > 64 * kn.extra_wave) xthreads = 64 * kn.extra_wave;
-            if (xthreads && !ctx->d_xstack)      // 16 waves x 32 levels x 64 lanes per CU: every case
-                PT_HIP(ctx, hipMalloc((void **)&ctx->d_xstack, (size_t)ctx->num_cus * 16 * 32 * 64 * sizeof(float)));
+            // 16 waves x 32 levels x 64 lanes per CU cover every case of ONE launch; launches of overlapped short calls run
+            // side by side (workgroup b of the next call starts on a CU while workgroup b of this one is still in its
+            // tail), so the context's stream and each of the two overlap slots get a region of their own
+            const size_t xstack_region = (size_t)ctx->num_cus * 16 * 32 * 64;
+            if (xthreads && !ctx->d_xstack)
+                PT_HIP(ctx, hipMalloc((void **)&ctx->d_xstack, 3 * xstack_region * sizeof(float)));
+            float *const xstack = ctx->d_xstack ? ctx->d_xstack + (size_t)(ctx->pipe_active + 1) * xstack_region : nullptr;
 #define PT_LAUNCH(SLOT, C, L, N) PT_LAUNCH_(SLOT, C, L, N, false, false)
 #define PT_LAUNCH_G(SLOT, C, N) do { \
             if (gen) { if (use_pair) PT_LAUNCH_(SLOT + 22, C, false, N, true, true); else PT_LAUNCH_(SLOT + 16, C, false, N, false, true); } \
@@ -2317,7 +2322,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
                 ctx->d_gstack, n_slots, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, seeds, \
                 ctx->d_samples, ctx->d_counters, ctx->d_work, \
                 order, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, \
-                (uint32_t)chunk, tune, top, threads, ctx->d_xstack); } while (0)
+                (uint32_t)chunk, tune, top, threads, xstack); } while (0)
             // slot of the variant in ctx->lds_attr: COUNT, LDSN, NEAR as bits; + 10 with pair lines, + 16 / + 22 for trees with
             // explicit child ids (without / with pair lines); 8, 9: wavefront; 28, 29: the per-ray kernels
             // two paths per lane need items of several frames (the two paths are two frames of one pixel): short launches,
@@ -2341,7 +2346,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
                 if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream)); \
                 hipLaunchKernelGGL((k_trace_dual<C, L>), dim3(ctx->num_cus), dim3(threads + xthreads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
                     n_slots, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, ctx->d_samples, ctx->d_counters, ctx->d_work, \
-                    order, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, (uint32_t)chunk, dt, top, threads, ctx->d_xstack); } while (0)
+                    order, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, (uint32_t)chunk, dt, top, threads, xstack); } while (0)
                 if (lds_nodes) { if (ctx->detailed) PT_LAUNCH_DUAL(31, true, true); else PT_LAUNCH_DUAL(30, false, true); }
                 else           { if (ctx->detailed) PT_LAUNCH_DUAL(19, true, false); else PT_LAUNCH_DUAL(18, false, false); }
 #undef PT_LAUNCH_DUAL

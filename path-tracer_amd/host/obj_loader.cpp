@@ -90,15 +90,17 @@ struct Cursor {
     bool at_end() const { return *p == '\0' || *p == '\r' || *p == '\n'; }
 };
 
-// 1-based / negative-relative OBJ index -> 0-based.  Zero is invalid, and so is anything that does not
-// name one of the `count` elements read so far (faces are triangulated from the vertices present when
-// their group is closed, so a reference can never point forward).
+// 1-based / negative-relative OBJ index -> 0-based.  Zero is invalid.  A negative index counts back from the
+// `count` elements read so far and must name one of them.  A positive index may point FORWARD (the reference's
+// parser does no range check, tiny_obj_loader.h fixIndex): it is checked later, against the elements present
+// when it is first dereferenced -- vertices when the face's group is closed and triangulated (faces_in_range),
+// normals at the end of the file (load_obj).
 bool fix_index(int idx, int count, int &out, bool dereferenced = true)
 {
-    if (idx > 0) out = idx - 1;
-    else if (idx < 0) out = count + idx;
-    else return false;
-    return !dereferenced || (out >= 0 && out < count);
+    if (idx > 0) { out = idx - 1; return true; }
+    if (idx == 0) return false;
+    out = count + idx;
+    return !dereferenced || out >= 0;
 }
 
 void skip_index_field(const char *&p) { p += std::strcspn(p, "/ \t\r"); }
@@ -146,6 +148,16 @@ void emit_triangle(Shape &shape, const Index &a, const Index &b, const Index &c,
     shape.indices.push_back(c);
     shape.material_ids.push_back(material);
     shape.smoothing_ids.push_back(smoothing);
+}
+
+// every vertex a face of the group names exists by now (the group is about to be triangulated from `v`)
+bool faces_in_range(const std::vector<Face> &faces, const std::vector<float> &v)
+{
+    const int nv = (int)(v.size() / 3);
+    for (const Face &face : faces)
+        for (const Index &c : face.corners)
+            if (c.v < 0 || c.v >= nv) return false;
+    return true;
 }
 
 // Appends the faces to the shape as triangles.  Polygons are ear-clipped in the
@@ -306,6 +318,7 @@ bool load_obj(const std::string &path, Mesh &out, std::string &err)
             const int next = (it == by_name.end()) ? -1 : it->second;
             if (next != material) {
                 // materials are per face: the faces read so far go into the current shape
+                if (!faces_in_range(group, out.vertices)) { err = "face names a vertex that does not exist when its group ends"; return false; }
                 append_faces(shape, group, material, name, out.vertices);
                 group.clear();
                 material = next;
@@ -320,6 +333,7 @@ bool load_obj(const std::string &path, Mesh &out, std::string &err)
                 if (m) { load_mtl(m, out.materials, by_name); break; }
             }
         } else if (t[0] == 'g' && is_blank(t[1])) {
+            if (!faces_in_range(group, out.vertices)) { err = "face names a vertex that does not exist when its group ends"; return false; }
             append_faces(shape, group, material, name, out.vertices);
             if (!shape.indices.empty()) out.shapes.push_back(shape);
             shape = Shape();
@@ -329,6 +343,7 @@ bool load_obj(const std::string &path, Mesh &out, std::string &err)
             names.token(b, e);
             name = std::string(b, e);
         } else if (t[0] == 'o' && is_blank(t[1])) {
+            if (!faces_in_range(group, out.vertices)) { err = "face names a vertex that does not exist when its group ends"; return false; }
             if (append_faces(shape, group, material, name, out.vertices)) out.shapes.push_back(shape);
             shape = Shape();
             group.clear();
@@ -346,8 +361,15 @@ bool load_obj(const std::string &path, Mesh &out, std::string &err)
             }
         }
     }
+    if (!faces_in_range(group, out.vertices)) { err = "face names a vertex that does not exist when its group ends"; return false; }
     const bool any = append_faces(shape, group, material, name, out.vertices);
     if (any || !shape.indices.empty()) out.shapes.push_back(shape);
+    // normals are read only after the whole file has been parsed (scene.cpp:134-290), so a face may name any
+    // normal of the file
+    const int nvn = (int)(out.normals.size() / 3);
+    for (const Shape &sh : out.shapes)
+        for (const Index &c : sh.indices)
+            if (c.vn >= nvn) { err = "face names a normal that the file does not have"; return false; }
     return true;
 }
 

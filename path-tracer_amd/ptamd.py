@@ -48,7 +48,7 @@ EXPORTS = (
     "pt_resize", "pt_upload_gbuffer", "pt_download_gbuffer", "pt_primary_hits", "pt_albedo_bytes",
     "pt_trace", "pt_trace_region", "pt_trace_frames", "pt_frame_seeds", "pt_get_frame_count", "pt_reset_accumulation",
     "pt_linear_sum_device_ptr", "pt_resolve",
-    "pt_comm_unique_id", "pt_comm_init_rank", "pt_comm_destroy", "pt_reduce_linear_sum",
+    "pt_comm_unique_id", "pt_comm_init_rank", "pt_comm_destroy", "pt_comm_count", "pt_reduce_linear_sum",
     "pt_download_output", "pt_download_display", "pt_output_device_ptr",
     "pt_set_stack_size", "pt_set_max_segments", "pt_set_traversal_order", "pt_set_trace_overlap", "pt_set_trace_schedule", "pt_set_trace_timing", "pt_get_trace_times", "pt_set_detailed_counters", "pt_get_counters", "pt_reset_counters", "pt_intersect",
 )
@@ -288,6 +288,12 @@ class Context:
 
     def comm_destroy(self):
         self._ck(self.L.pt_comm_destroy(self.h))
+
+    def comm_count(self):
+        """Ranks of this context's RCCL communicator (ncclCommCount), 0 without one."""
+        n = C.c_int(0)
+        self._ck(self.L.pt_comm_count(self.h, C.byref(n)))
+        return n.value
 
     def reduce_linear_sum(self, nccl_comm=None):
         self._ck(self.L.pt_reduce_linear_sum(self.h, C.c_void_p(nccl_comm)))

@@ -70,3 +70,23 @@ def test_bench_command_line():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in out.stdout
+
+
+def test_bench_refuses_a_rank_count_other_than_the_one_asked_for():
+    """--gpus N under a launcher that made another number of ranks must fail, not measure that other number."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 2 and "refusing" in out.stderr and out.stdout.strip() == ""
+
+
+def test_bench_without_a_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts a 2-rank torch.distributed.run job (which cannot
+    succeed without GPUs: the point here is that it is started, and that its failure is the parent's exit code)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["PTAMD_BENCH_WATCHDOG_S"] = "60"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-build"],
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert "starting 2 ranks" in out.stderr and "--nproc-per-node 2" in out.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]

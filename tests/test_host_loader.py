@@ -114,17 +114,30 @@ def test_polygon_and_material_rules(host, tmp_path, monkeypatch):
         host.pth_scene_free(s)
 
 
-@pytest.mark.parametrize("face", ["f 9999 1 2", "f 1 2 4", "f -4 1 2", "f 1//2 2//1 3//1", "f 1//-2 2//1 3//1", "f 0 1 2"])
+@pytest.mark.parametrize("face", ["f 9999 1 2", "f 1 2 5", "f -4 1 2", "f 1//3 2//1 3//1", "f 1//-2 2//1 3//1", "f 0 1 2"])
 def test_face_indices_outside_the_arrays_are_errors(host, tmp_path, monkeypatch, face):
-    """A face may only name vertices and normals read so far: too large, forward, too negative and zero
-    indices fail the load instead of reading outside the arrays."""
+    """Too large, too negative and zero indices fail the load instead of reading outside the arrays: a vertex must
+    exist when the face's group is closed (that is when the face is triangulated), a normal by the end of the file."""
     monkeypatch.chdir(tmp_path)
-    (tmp_path / "bad.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\n" + face + "\nv 5 5 5\n")
+    (tmp_path / "bad.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\n" + face + "\nv 5 5 5\nvn 0 1 0\n")
     assert not host.pth_scene_load(b"bad.obj")
     (tmp_path / "good.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf -3//-1 -2//1 3//1\n")
     s = host.pth_scene_load(b"good.obj")
     assert s and host.pth_scene_triangle_count(s) == 1
     host.pth_scene_free(s)
+
+
+def test_forward_references_are_accepted_as_the_reference_parser_does(host, tmp_path, monkeypatch):
+    """tinyobjloader's fixIndex does no range check and the reference reads the arrays only after the parse
+    (scene.cpp:134-290), so a face may name a vertex or normal that the file defines later."""
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "fwd.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//2 2//1 4//1\nv 5 5 5\nvn 0 1 0\n")
+    s = host.pth_scene_load(b"fwd.obj")
+    assert s and host.pth_scene_triangle_count(s) == 1
+    host.pth_scene_free(s)
+    # ... but a vertex defined only after the face's group has been closed is not there when the face is triangulated
+    (tmp_path / "late.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 4\ng next\nv 5 5 5\nf 1 2 3\n")
+    assert not host.pth_scene_load(b"late.obj")
 
 
 def test_more_than_sixteen_materials_are_refused_by_the_facade(tmp_path, monkeypatch):

@@ -665,6 +665,36 @@ def test_overlapped_short_calls_equal_serial_ones(gpu_ctx_factory, golden, monke
     assert np.array_equal(_bits(a[3]), _bits(old))
 
 
+def test_overlapped_single_frame_calls_at_full_size(gpu_ctx_factory, golden):
+    """scene04 at 1162x1008, one frame per call (the reference's own run loop), calls overlapped on the two internal
+    streams: every wave of every CU is busy, the sixteenth wave of a workgroup keeps its stack entries in global memory,
+    and workgroup b of call k+1 starts on a CU while workgroup b of call k is still in its tail -- so each of the launches
+    in flight needs stack rows of its own.  Twelve frames against the same calls with overlap off, and the first three
+    against the oracle."""
+    W, H, N = 1162, 1008, 12
+    g = golden["scene04"]
+    seeds = ptamd.frame_seeds(1, 0, N)
+    images = []
+    for overlap in (True, False):
+        ctx = gpu_ctx_factory()
+        ctx.set_trace_overlap(overlap)
+        sc, gb, _ = _setup(ctx, g, W, H)
+        snaps = []
+        for f in range(N):
+            ctx.trace(f, seeds[f])
+            if f == 2:
+                snaps.append(ctx.output().copy())
+        snaps.append(ctx.output().copy())
+        snaps.append(ctx.counters())
+        images.append(snaps)
+    a, b = images
+    assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(_bits(a[1]), _bits(b[1])) and a[2] == b[2]
+    old = np.zeros((H, W, 4), np.float32)
+    for f in range(3):
+        old = orc.trace_frame(sc, gb, f, seeds[f], old)[0]
+    assert np.array_equal(_bits(a[0]), _bits(old))
+
+
 @pytest.mark.parametrize("schedule", [ptamd.PT_SCHEDULE_PERSISTENT, "dual"])
 @pytest.mark.parametrize("n", [2700, 3100, 9000])
 def test_trees_around_the_lds_capacity(gpu_ctx_factory, monkeypatch, n, schedule):
