@@ -19,7 +19,8 @@ replicas), and a bounded CPU baseline (the oracle, rank 0, N = 1 only).
 3840x2160, at most 8 rays per path, full-resolution codes, tree over the Morton codes (--topology index: the
 reference's index-keyed tree), nearest child first (--near-first 0: the reference's order), deep stack
 (NON-PARITY options, see include/ptamd.h).
-One STEP = one launch of 2 frames.  Node records are read from global memory: this one is bound by HBM.
+One STEP = one launch of 2 frames.  Node records are read from global memory: this one is bound by the rate at which the
+memory system serves dependent random requests.
 
 `python bench.py --gpus N` with N > 1 and no launcher (WORLD_SIZE unset) starts its own N ranks through
 torch.distributed.run before anything touches a GPU; under a launcher whose WORLD_SIZE differs from --gpus it refuses.
@@ -60,8 +61,37 @@ STAGE_BYTES = {
     "tree_only": {"bounds": 80 + 32, "morton": 32 + 4, "sort": (4 + 8) + (4 + 8 + 4), "refit": 4 + 32 + 64},
     "default": {"bounds": 80 + 12, "morton": 12 + 4, "sort": (4 + 8) + (4 + 8 + 4), "refit": 4 + 80 + 64 + 96},
 }
-PROFILE_TRACE = os.path.join(ROOT, "profiles", "r02_trace_pmc.json")
-PROFILE_BUILD = os.path.join(ROOT, "profiles", "r02_build_pmc.json")
+PROFILE_BUILD = os.path.join(ROOT, "profiles", "r03_build_pmc.json")
+# counter profiles of the trace kernel, one per workload the benchmark can run (scripts/pmc_target.py takes them on
+# the same scene, image size and launch length): key = (scene, width, height, frames per launch)
+PROFILE_TRACE = {
+    ("scene04", 1162, 1008, 128): os.path.join(ROOT, "profiles", "r03_trace_pmc.json"),
+    ("scene02", 3840, 2160, 128): os.path.join(ROOT, "profiles", "r03_trace_scene02_4k_pmc.json"),
+    ("scene03", 3840, 2160, 128): os.path.join(ROOT, "profiles", "r03_trace_scene03_4k_pmc.json"),
+}
+# ... and of the 100M-triangle soup at 3840x2160, 2-frame launches: key = (topology, nearest child first)
+PROFILE_SOUP = {
+    ("index", 0): os.path.join(ROOT, "profiles", "r03_soup100m_pmc.json"),
+    ("index", 1): os.path.join(ROOT, "profiles", "r03_soup100m_near_first_pmc.json"),
+    ("morton", 1): os.path.join(ROOT, "profiles", "r03_soup100m_morton_pmc.json"),
+}
+# Dependent random record reads per second that the memory system serves (scripts/micro/random_records.hip,
+# profiles/r03_random_records.txt): the roof of traversals whose node array is far larger than the caches.
+# (array MiB, G records/s); between the points the rate is interpolated in log(size)
+RANDOM_RECORD_RATE = ((160, 54.0), (1280, 54.7), (6400, 23.7), (12800, 21.5))
+
+
+def random_record_peak(array_bytes):
+    import math
+    mib = array_bytes / 2.0 ** 20
+    pts = RANDOM_RECORD_RATE
+    if mib <= pts[0][0]:
+        return pts[0][1]
+    for (a, ra), (b, rb) in zip(pts, pts[1:]):
+        if mib <= b:
+            t = (math.log(mib) - math.log(a)) / (math.log(b) - math.log(a))
+            return ra + t * (rb - ra)
+    return pts[-1][1]
 KERNEL_SOURCES = ("path-tracer_amd/csrc/trace_kernels.hip", "path-tracer_amd/csrc/build_kernels.hip",
                   "path-tracer_amd/csrc/api.hip", "path-tracer_amd/csrc/pt_internal.hpp", "include/ptamd_math.h")
 
@@ -121,6 +151,35 @@ def device_soup(n, seed=12345, scale=1.0, emitter_every=0):
     ids[:, 19] = -1
     torch.cuda.synchronize()
     return out
+
+
+def setup_soup_scene(ctx, n, W, H, topology, near_first):
+    """The largest named configuration on `ctx`: an n-triangle soup generated on the device (every rank: the same
+    scene), 4 diffuse materials + 1 emitter, full-resolution codes, deep stack, at most 8 rays per path; built twice
+    (the second build's times are returned), image resized, G-buffer cast.  Shared with scripts/pmc_target.py so
+    that counter profiles are taken on exactly the benchmark's workload."""
+    import ptamd
+    keep = device_soup(n, seed=2024, scale=100.0, emitter_every=16)
+    ctx.upload_primitives_device(keep.data_ptr(), n)
+    cb = np.zeros(1, dtype=ptamd.CB_RADIX)
+    cb["node_count"] = n
+    cb["pos"][0] = (50.0, 50.0, 300.0)
+    for k, kd in enumerate(((0.7, 0.6, 0.5), (0.3, 0.6, 0.7), (0.6, 0.7, 0.3), (0.75, 0.75, 0.75))):
+        cb["mats"][0][k]["ns"] = 1; cb["mats"][0][k]["ni"] = 1; cb["mats"][0][k]["kd"][:3] = kd
+    cb["mats"][0][4]["ke"] = 10; cb["mats"][0][4]["ns"] = 1; cb["mats"][0][4]["ni"] = 1; cb["mats"][0][4]["kd"][:3] = (1, 1, 1)
+    ctx.set_constants(cb)
+    soup_flags = ptamd.PT_BUILD_MORTON_FULL | (ptamd.PT_BUILD_TOPOLOGY_MORTON if topology == "morton" else 0)
+    ctx.build(soup_flags)
+    ctx.build(soup_flags)
+    scene_build = ctx.build_times()
+    ctx.resize(W, H)
+    ctx.set_stack_size(32)
+    ctx.set_max_segments(8)
+    ctx.set_traversal_order(ptamd.PT_TRAVERSAL_NEAR_FIRST if near_first else ptamd.PT_TRAVERSAL_REFERENCE)
+    cam = ptamd.default_camera(eye=(50.0, 50.0, 300.0), at=(50.0, 50.0, 50.0))
+    cam.zfar = 1000.0
+    ctx.primary_hits(cam, ptamd.albedo_table([list(cb["mats"][0][m]["kd"][:3]) for m in range(16)]))
+    return keep, cb, scene_build
 
 
 class _DevArray:
@@ -251,13 +310,13 @@ def cpu_baseline(g, W, H, budget_s=10.0, max_frames=32):
                       f"CPU LBVH build of its {len(prims)} triangles {build_s * 1e3:.1f} ms single-threaded"}
 
 
-def trace_roofline_scene(kern_avg_ms, rays_per_launch, bytes_per_ray, launches_per_step, profile_applies=True):
+def trace_roofline_scene(kern_avg_ms, rays_per_launch, bytes_per_ray, launches_per_step, profile_path):
     """Roofline of the trace kernel with the tree in LDS.  The kernel is bound by vector-instruction issue:
     `achieved` = vector wave-instructions per launch (hardware counter SQ_INSTS_VALU of the committed profile,
     taken on this same launch shape) over the launch duration measured HERE with HIP events; `peak` = one wave64
     instruction per 2 clocks per SIMD.  The algorithmic traversal bytes are served by LDS and L1/L2 and reported
     as such, not as an HBM fraction."""
-    prof = load_profile(PROFILE_TRACE)
+    prof = load_profile(profile_path) if profile_path else None
     # the kernel the library runs for trees in LDS: two paths per lane (k_trace_dual) unless PTAMD_DUAL=0
     kernel = "k_trace_persistent" if os.environ.get("PTAMD_DUAL") == "0" else "k_trace_dual"
     k = (prof or {}).get(kernel)
@@ -266,10 +325,10 @@ def trace_roofline_scene(kern_avg_ms, rays_per_launch, bytes_per_ray, launches_p
            "launch_ms_avg": kern_avg_ms, "launches_per_step": launches_per_step,
            "algorithmic_bytes_served_on_chip_GBps": on_chip,
            "peak_note": f"{SIMDS} SIMDs x {CLOCK_GHZ} GHz / 2 clocks per wave64 instruction"}
-    if not k or "SQ_INSTS_VALU" not in k or not profile_applies:
+    if not k or "SQ_INSTS_VALU" not in k:
         out.update({"achieved": None, "frac": None, "traffic": None,
-                    "note": "no counter profile of THIS workload under profiles/ (the committed one is scene04 at 1162x1008, "
-                            "128-frame launches); same kernel, see the default configuration's line for its roofline"})
+                    "note": "no counter profile of THIS workload (scene, image size, frames per launch) under profiles/; "
+                            "same kernel, see the default configuration's line for its roofline"})
         return out
     valu = k["SQ_INSTS_VALU"]
     achieved = valu / (kern_avg_ms * 1e-3) / 1e9
@@ -283,7 +342,7 @@ def trace_roofline_scene(kern_avg_ms, rays_per_launch, bytes_per_ray, launches_p
         "hbm": {"bytes_per_launch": k.get("hbm_bytes_per_launch"),
                 "GBps": (k.get("hbm_bytes_per_launch", 0) / (kern_avg_ms * 1e-3) / 1e9) if k.get("hbm_bytes_per_launch") else None,
                 "peak": HBM_PEAK_GBS},
-        "profile": {"file": os.path.relpath(PROFILE_TRACE, ROOT), "taken_with_these_kernel_sources": prof["_current"],
+        "profile": {"file": os.path.relpath(profile_path, ROOT), "taken_with_these_kernel_sources": prof["_current"],
                     "meta": prof.get("_meta")},
     })
     if "SQ_INSTS_LDS" in k:
@@ -324,6 +383,45 @@ def launch_ranks(n):
         print(f"bench.py: the {n}-rank job printed {lines} JSON lines, expected exactly one", file=sys.stderr)
         return 3
     return rc
+
+
+def trace_roofline_soup(kern_avg_ms, rays_per_launch, visits_per_ray, bytes_per_ray, launches_per_step, n, profile_path):
+    """Roofline of the trace kernel on a tree far larger than the caches.  Every node visit below the cached top of the tree
+    is a dependent read of one record at a random address, and the memory system serves a bounded number of such
+    requests per second whatever their size up to a 128-byte line (micro-benchmark: RANDOM_RECORD_RATE).  `achieved` =
+    memory-side read requests per launch (hardware counter TCC_EA0_RDREQ of the committed profile of this workload)
+    over the launch duration measured HERE with HIP events; `peak` = the micro-benchmark's rate for an array of the
+    size of this tree's child lines (128 B per node).  `traffic` = HBM bytes per launch from the same profile.  The
+    algorithmic figure (36 B per node visit + 36 B per triangle test) is kept, labelled as such."""
+    prof = load_profile(profile_path) if profile_path else None
+    k = (prof or {}).get("k_trace_persistent")
+    array_bytes = n * 128
+    peak = random_record_peak(array_bytes)
+    algorithmic = rays_per_launch * bytes_per_ray / (kern_avg_ms * 1e-3) / 1e9
+    out = {"bound": "memory requests", "unit": "G requests/s", "peak": peak, "kernel": "k_trace_persistent (node records in global memory)",
+           "launch_ms_avg": kern_avg_ms, "launches_per_step": launches_per_step,
+           "peak_note": f"dependent random record reads from an array of {array_bytes / 2 ** 30:.1f} GiB (the tree's 128-byte child lines), "
+                        "scripts/micro/random_records.hip; table RANDOM_RECORD_RATE in bench.py, profiles/r03_random_records.txt",
+           "node_visits_per_s_G": rays_per_launch * visits_per_ray / (kern_avg_ms * 1e-3) / 1e9,
+           "algorithmic_GBps": algorithmic, "algorithmic_frac_of_hbm_peak": algorithmic / HBM_PEAK_GBS,
+           "algorithmic_note": "36 B per node visit + 36 B per triangle test over the launch time: NOT memory traffic (the top of "
+                               "the tree is served by L1/L2, and a visit below it moves a whole line)"}
+    if not k or "TCC_EA0_RDREQ_sum" not in k:
+        out.update({"achieved": None, "frac": None, "traffic": None,
+                    "note": "no counter profile of THIS workload (triangles, image size, frames per launch, options) under profiles/"})
+        return out
+    req = k["TCC_EA0_RDREQ_sum"]
+    achieved = req / (kern_avg_ms * 1e-3) / 1e9
+    out.update({"achieved": achieved, "frac": achieved / peak, "memory_read_requests_per_launch": req,
+                "requests_per_ray": req / rays_per_launch,
+                "traffic": k.get("hbm_bytes_per_launch") if prof["_current"] else None,
+                "hbm_GBps": (k["hbm_bytes_per_launch"] / (kern_avg_ms * 1e-3) / 1e9) if k.get("hbm_bytes_per_launch") else None,
+                "l2_hit_rate": (k["TCC_HIT_sum"] / k["TCC_REQ_sum"]) if k.get("TCC_REQ_sum") else None,
+                "profile": {"file": os.path.relpath(profile_path, ROOT), "taken_with_these_kernel_sources": prof["_current"],
+                            "meta": prof.get("_meta")}})
+    if not prof["_current"]:
+        out["note"] = "counter profile was taken with other kernel sources: request counts may be stale, traffic withheld"
+    return out
 
 
 def main():
@@ -398,26 +496,7 @@ def main():
     if soup_mode:
         W, H = args.width or 3840, args.height or 2160
         n = args.soup_tris
-        keep = device_soup(n, seed=2024 + rank * 0, scale=100.0, emitter_every=16)      # every rank: the same scene
-        ctx.upload_primitives_device(keep.data_ptr(), n)
-        cb = np.zeros(1, dtype=ptamd.CB_RADIX)
-        cb["node_count"] = n
-        cb["pos"][0] = (50.0, 50.0, 300.0)
-        for k, kd in enumerate(((0.7, 0.6, 0.5), (0.3, 0.6, 0.7), (0.6, 0.7, 0.3), (0.75, 0.75, 0.75))):
-            cb["mats"][0][k]["ns"] = 1; cb["mats"][0][k]["ni"] = 1; cb["mats"][0][k]["kd"][:3] = kd
-        cb["mats"][0][4]["ke"] = 10; cb["mats"][0][4]["ns"] = 1; cb["mats"][0][4]["ni"] = 1; cb["mats"][0][4]["kd"][:3] = (1, 1, 1)
-        ctx.set_constants(cb)
-        soup_flags = ptamd.PT_BUILD_MORTON_FULL | (ptamd.PT_BUILD_TOPOLOGY_MORTON if args.topology == "morton" else 0)
-        ctx.build(soup_flags)
-        ctx.build(soup_flags)
-        scene_build = ctx.build_times()
-        ctx.resize(W, H)
-        ctx.set_stack_size(32)
-        ctx.set_max_segments(8)
-        ctx.set_traversal_order(ptamd.PT_TRAVERSAL_NEAR_FIRST if args.near_first else ptamd.PT_TRAVERSAL_REFERENCE)
-        cam = ptamd.default_camera(eye=(50.0, 50.0, 300.0), at=(50.0, 50.0, 50.0))
-        cam.zfar = 1000.0
-        ctx.primary_hits(cam, ptamd.albedo_table([list(cb["mats"][0][m]["kd"][:3]) for m in range(16)]))
+        keep, cb, scene_build = setup_soup_scene(ctx, n, W, H, args.topology, args.near_first)
         fpb = args.soup_frames
     else:
         W, H = args.width or 1162, args.height or 1008
@@ -550,18 +629,12 @@ def main():
     assert float(alpha.min().item()) == float(total_frames) == float(alpha.max().item()), "accumulation count mismatch"
 
     if soup_mode:
-        # node records and triangles come from global memory: HBM-bound; algorithmic bytes over kernel time
-        achieved = rays_per_launch * bytes_per_ray / (kern_avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None, "kernel": "k_trace_persistent (node records in global memory)",
-                    "launch_ms_avg": kern_avg_ms, "launches_per_step": len(kern_ms) // args.steps,
-                    "node_visits_per_s_G": rays_per_launch * visits_per_ray / (kern_avg_ms * 1e-3) / 1e9,
-                    "note": "algorithmic bytes = 36 B per node visit + 36 B per triangle test; a visit fetches one 64-byte "
-                            "record at a random address of a node array far larger than the caches"}
+        roofline = trace_roofline_soup(kern_avg_ms, rays_per_launch, visits_per_ray, bytes_per_ray, len(kern_ms) // args.steps,
+                                       int(ctx.n), PROFILE_SOUP.get((args.topology, int(bool(args.near_first))))
+                                       if (W, H, fpb, int(ctx.n)) == (3840, 2160, 2, 100_000_000) else None)
     else:
         roofline = trace_roofline_scene(kern_avg_ms, rays_per_launch, bytes_per_ray, len(kern_ms) // args.steps,
-                                        profile_applies=(args.scene == "scene04" and (W, H) == (1162, 1008) and
-                                                         len(kern_ms) == args.steps))
+                                        PROFILE_TRACE.get((args.scene, W, H, fpb)) if len(kern_ms) == args.steps else None)
 
     builds = {}
     if not args.no_build and not soup_mode:

@@ -51,6 +51,19 @@ struct Ray {
 // the mask into 0/1 per lane and compares again: two vector instructions per vote)
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
+// Staging of one launch, layout [pixel][frame of the launch]: the radiance sample of every path (three floats; alpha is
+// always 1) and, in an array of its own, the path's seed.  Consecutive frames of a pixel are 12 and 4 bytes apart, so
+// the frames of a work item fill whole cache lines.
+struct Staging {
+    float *__restrict__ rgb;
+    uint32_t *__restrict__ seed;
+};
+__device__ __forceinline__ void put_sample(const Staging &st, size_t path, float r, float g, float b)
+{
+    float *d = st.rgb + path * 3;
+    d[0] = r; d[1] = g; d[2] = b;
+}
+
 struct LaneCounters {
     unsigned paths = 0, rays = 0, node_visits = 0, box_tests = 0, tri_tests = 0;
 };
@@ -354,12 +367,12 @@ struct TopLevels { int k0, nodes; int off[33]; };    // itr_limit: a path ends w
 
 // ---------------------------------------------------------------------------
 // Path seeds of one launch: seed(pixel, frame) = rand_init(pixel id, g_random[0] of the frame)
-// (ray_tracing.hlsl:410, helpers.hlsli:5-19), written into the w component of the path's sample slot.
+// (ray_tracing.hlsl:410, helpers.hlsli:5-19), written into the path's slot of the staging seed array.
 // The 16-round hash costs ~290 instructions; inside the persistent kernel a wave would run it in
 // nearly every refill round for the few lanes that start a path, here every lane does useful work.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_path_seeds(int W, unsigned npix, uint32_t count, const uint32_t *__restrict__ seeds,
-                                                    float4 *__restrict__ samples, int frame_lanes_log2)
+                                                    Staging samples, int frame_lanes_log2)
 {
     // A workgroup covers 256 >> frame_lanes_log2 pixels; the lanes of a pixel stride over its frames, so a
     // pixel's slots are written side by side and no index needs a division by `count`.
@@ -370,7 +383,7 @@ __global__ __launch_bounds__(256) void k_path_seeds(int W, unsigned npix, uint32
         // ray_tracing.hlsl:410: uint(launchIndex.x + launchIndex.y * viewportDims.x), in float
         const uint32_t pixel_id = (uint32_t)((float)x + (float)y * (float)W);
         for (unsigned fl = fl0; fl < count; fl += frame_lanes)
-            samples[(size_t)px * count + fl] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rand_init(pixel_id, seeds[fl])));
+            samples.seed[(size_t)px * count + fl] = rand_init(pixel_id, seeds[fl]);
     }
 }
 
@@ -430,7 +443,7 @@ __device__ __forceinline__ void persistent_paths(const SceneView sc, const TriIs
                                                  const float4 *__restrict__ world_tex,
                                                  const uint32_t first_frame, const uint32_t count,
                                                  const uint32_t *__restrict__ seeds,
-                                                 float4 *__restrict__ samples, DevCounters *__restrict__ counters,
+                                                 const Staging samples, DevCounters *__restrict__ counters,
                                                  unsigned *__restrict__ work_counter,
                                                  const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
                                                  const uint32_t chunk, const Tuning tune, const TopLevels top,
@@ -489,7 +502,7 @@ __device__ __forceinline__ void persistent_paths(const SceneView sc, const TriIs
 
     // the radiance sample of local frame fl (ray_tracing.hlsl:396-411: `multi` or black)
     auto emit = [&](const pt_f3 &color, uint32_t fl) {
-        samples[(size_t)px * count + fl] = make_float4(color.x, color.y, color.z, 1.0f);
+        put_sample(samples, (size_t)px * count + fl, color.x, color.y, color.z);
     };
 
     // lanes to serve in a refill: K_IDLE always, K_NOITEM while the queue has items
@@ -590,8 +603,8 @@ __device__ __forceinline__ void persistent_paths(const SceneView sc, const TriIs
                         if (f < f_end) {
                             // new path of frame f (ray_tracing.hlsl:348-370, 410)
                             cnt.paths++;
-                            // rand_init(pixel, seed of the frame), left in the path's sample slot by k_path_seeds
-                            seed = __float_as_uint(samples[(size_t)px * count + f].w);
+                            // rand_init(pixel, seed of the frame), left in the path's seed slot by k_path_seeds
+                            seed = samples.seed[(size_t)px * count + f];
                             multi = multi0;
                             itr = 1;
                             ray.o = hit_pos;
@@ -882,7 +895,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                                                     const float4 *__restrict__ world_tex,
                                                     uint32_t first_frame, uint32_t count,
                                                     const uint32_t *__restrict__ seeds,
-                                                    float4 *__restrict__ samples, DevCounters *__restrict__ counters,
+                                                    const Staging samples, DevCounters *__restrict__ counters,
                                                     unsigned *__restrict__ work_counter,
                                                     const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
                                                     uint32_t chunk, Tuning tune, TopLevels top, int lds_threads, float *__restrict__ xstack)
@@ -971,7 +984,7 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
                                            const float4 *__restrict__ normal_tex,
                                            const float4 *__restrict__ world_tex,
                                            const uint32_t first_frame, const uint32_t count,
-                                           float4 *__restrict__ samples, DevCounters *__restrict__ counters,
+                                           const Staging samples, DevCounters *__restrict__ counters,
                                            unsigned *__restrict__ work_counter,
                                            const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
                                            const uint32_t chunk, const Tuning &tune, const TopLevels &top,
@@ -1026,7 +1039,7 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
     float p_q0 = 0, p_q1 = 0, p_q2 = 0;
 
     auto emit = [&](const pt_f3 &color, uint32_t fl) {
-        samples[(size_t)px * count + fl] = make_float4(color.x, color.y, color.z, 1.0f);
+        put_sample(samples, (size_t)px * count + fl, color.x, color.y, color.z);
     };
     // The finished ray of the traversal slot (if any) moves to the parked slot, its origin advanced to the hit point
     // (ray_tracing.hlsl:376); the parked ray (if any) moves to the traversal slot.  For lanes that are not traversing and
@@ -1159,7 +1172,7 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
                     if (p_state == P_START) {
                         // new path of frame f (ray_tracing.hlsl:348-370, 410)
                         cnt.paths++;
-                        p_seed = __float_as_uint(samples[(size_t)px * count + f].w);
+                        p_seed = samples.seed[(size_t)px * count + f];
                         p_multi = multi0;
                         p_itr = 1;
                         p_o = hit_pos;
@@ -1327,7 +1340,7 @@ __global__ __launch_bounds__(1024) void k_trace_dual(SceneView sc, const TriIsec
                                               const float4 *__restrict__ normal_tex,
                                               const float4 *__restrict__ world_tex,
                                               uint32_t first_frame, uint32_t count,
-                                              float4 *__restrict__ samples, DevCounters *__restrict__ counters,
+                                              const Staging samples, DevCounters *__restrict__ counters,
                                               unsigned *__restrict__ work_counter,
                                               const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
                                               uint32_t chunk, Tuning tune, TopLevels top, int lds_threads, float *__restrict__ xstack)
@@ -1444,7 +1457,7 @@ __global__ __launch_bounds__(256) void k_wf_first(SceneView sc, int W, int H,
                                                   const float4 *__restrict__ world_tex,
                                                   uint32_t first_frame, uint32_t count,
                                                   const uint32_t *__restrict__ seeds,
-                                                  float4 *__restrict__ samples,
+                                                  const Staging samples,
                                                   PathRec *__restrict__ queue, unsigned *__restrict__ qcount,
                                                   unsigned seg_size, DevCounters *__restrict__ counters)
 {
@@ -1486,7 +1499,7 @@ __global__ __launch_bounds__(256) void k_wf_first(SceneView sc, int W, int H,
                     color = multi;
                 }
             }
-            if (!cont) samples[slot] = make_float4(color.x, color.y, color.z, 1.0f);
+            if (!cont) put_sample(samples, slot, color.x, color.y, color.z);
         }
         const unsigned seg = base / seg_size;          // seg_size is a multiple of the block size
         wf_append(cont, rec, queue + (size_t)seg * seg_size, qcount + seg * WF_CSTRIDE);
@@ -1499,7 +1512,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(SceneView sc, const PathRec *_
                                                   const unsigned *__restrict__ count_in,
                                                   PathRec *__restrict__ queue_out, unsigned *__restrict__ count_out,
                                                   unsigned seg_size,
-                                                  float4 *__restrict__ samples, uint32_t first_frame, uint32_t count,
+                                                  const Staging samples, uint32_t first_frame, uint32_t count,
                                                   int itr_limit)
 {
     // blockIdx.y = segment; the blocks of a segment stride over its records
@@ -1551,7 +1564,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(SceneView sc, const PathRec *_
                     }
                 }
             }
-            if (!cont) samples[slot] = make_float4(color.x, color.y, color.z, 1.0f);
+            if (!cont) put_sample(samples, slot, color.x, color.y, color.z);
         }
         wf_append(cont, rec, queue_out + seg_base, count_out + seg * WF_CSTRIDE);
     }
@@ -1749,18 +1762,19 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
 // in order.  LITERAL: ray_tracing.hlsl:412-419 on `output` / `old` plus the UNORM8 copy;
 // LINEAR: running float sum, alpha counts samples.
 // A lane owns one pixel (the recurrence is sequential in the frame index), but a pixel's frames
-// are 16 bytes apart while neighbouring pixels are `count`*16 bytes apart, so the wave loads
-// tiles of 64 pixels x 8 frames with 8 lanes per pixel (128 contiguous bytes each) and hands
+// are 12 bytes apart while neighbouring pixels are `count`*12 bytes apart, so the wave loads
+// tiles of 64 pixels x 8 frames with 8 lanes per pixel (96 contiguous bytes each) and hands
 // them to the owning lanes through LDS.
 constexpr int ACC_FRAMES = 8;
+constexpr int ACC_ROW = ACC_FRAMES * 3 + 1;       // floats per pixel in the LDS tile; odd: lanes of a wave land in different banks
 
 template <bool LINEAR>
-__global__ __launch_bounds__(256) void k_accumulate(const float4 *__restrict__ samples, size_t npix,
+__global__ __launch_bounds__(256) void k_accumulate(const float *__restrict__ samples, size_t npix,
                                                     uint32_t first_frame, uint32_t count,
                                                     float4 *__restrict__ output, uint8_t *__restrict__ display,
                                                     float4 *__restrict__ linear, int W, int4 region)
 {
-    __shared__ float4 tile[4][64][ACC_FRAMES + 1];        // +1: lanes of a wave land in different banks
+    __shared__ float tile[4][64][ACC_ROW];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t p0 = (size_t)blockIdx.x * 256 + (size_t)wave * 64;       // the wave's first pixel
     const size_t p = p0 + lane;
@@ -1779,13 +1793,19 @@ __global__ __launch_bounds__(256) void k_accumulate(const float4 *__restrict__ s
         for (int j = 0; j < 8; j++) {
             const int pl = (lane >> 3) + 8 * j;                           // pixel within the wave's 64
             const uint32_t k = k0 + (lane & 7);
-            if (p0 + pl < npix && k < count) tile[wave][pl][lane & 7] = samples[(p0 + pl) * count + k];
+            if (p0 + pl < npix && k < count) {
+                const float *src = samples + ((p0 + pl) * count + k) * 3;
+                float *dst = &tile[wave][pl][(lane & 7) * 3];
+                const float r = src[0], g = src[1], b = src[2];
+                dst[0] = r; dst[1] = g; dst[2] = b;
+            }
         }
         __builtin_amdgcn_wave_barrier();                                   // the tile is private to the wave
         const uint32_t kn = min((uint32_t)ACC_FRAMES, count - k0);
         if (owner) {
             for (uint32_t kk = 0; kk < kn; kk++) {
-                const float4 c = tile[wave][lane][kk];
+                const float *t = &tile[wave][lane][kk * 3];
+                const float4 c = make_float4(t[0], t[1], t[2], 1.0f);
                 if (LINEAR) {
                     acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += 1.0f;
                 } else {
@@ -2047,12 +2067,23 @@ static int lds_resident_threads(const pt_context *ctx, int *levels_out, size_t *
     return (int)t;
 }
 
-// Frames per kernel launch: the samples of one launch are staged as [pixel][frame] float4 (a lane writes the frames of its item side by side) and
+// Frames per kernel launch: the samples of one launch are staged as [pixel][frame], 16 bytes per path (three floats of radiance and, in
+// an array of its own, the path's seed; a lane writes the frames of its item side by side) and
 // folded into the images by k_accumulate.  The staging buffer is capped (below), at 1 GiB (2^26 paths) for
 // the wavefront schedule, whose queues take another 112 bytes per path.
+constexpr size_t STAGING_BYTES_PER_PATH = 3 * sizeof(float) + sizeof(uint32_t);
+// the two arrays of a staging buffer that holds `frames` frames of `npix` pixels
+static Staging staging_view(float4 *base, uint32_t frames, size_t npix)
+{
+    Staging st;
+    st.rgb = reinterpret_cast<float *>(base);
+    st.seed = reinterpret_cast<uint32_t *>(st.rgb + 3 * (size_t)frames * npix);
+    return st;
+}
+
 static uint32_t frames_per_launch(const pt_context *ctx, uint32_t count, bool wavefront)
 {
-    const size_t per_frame = (size_t)ctx->W * ctx->H * sizeof(float4);
+    const size_t per_frame = (size_t)ctx->W * ctx->H * STAGING_BYTES_PER_PATH;
     // persistent schedule: up to an eighth of the device's memory (36 GiB of 288), at least 4 GiB -- at
     // 3840x2160 a 128-frame launch (17 GB of samples) is 6 % faster than four 32-frame launches
     size_t bytes = wavefront ? ((size_t)1 << 30) : (ctx->samples_cap_bytes > ((size_t)4 << 30) ? ctx->samples_cap_bytes : ((size_t)4 << 30));
@@ -2207,9 +2238,10 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
         if (ctx->d_samples) (void)hipFree(ctx->d_samples);
         ctx->d_samples = nullptr;
         ctx->samples_frames = 0;
-        PT_HIP(ctx, hipMalloc((void **)&ctx->d_samples, (size_t)per_launch * npix * sizeof(float4)));
+        PT_HIP(ctx, hipMalloc((void **)&ctx->d_samples, (size_t)per_launch * npix * STAGING_BYTES_PER_PATH));
         ctx->samples_frames = per_launch;
     }
+    const Staging staging = staging_view(ctx->d_samples, ctx->samples_frames, npix);
     if (wavefront && ctx->wf_paths < (size_t)per_launch * npix) {
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int k = 0; k < 2; k++) { if (ctx->d_wf_queue[k]) (void)hipFree(ctx->d_wf_queue[k]); ctx->d_wf_queue[k] = nullptr; }
@@ -2265,7 +2297,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             if (int rc = ensure_lds_limit(ctx, 9, &k_wf_extend<true>, lds_bytes)) return rc;
             if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream));
             hipLaunchKernelGGL(k_wf_first, fgrid, dim3(256), 0, ctx->stream, sv, ctx->W, ctx->H, ctx->d_diffuse, ctx->d_normal,
-                               ctx->d_world, first, cnt, seeds, ctx->d_samples, queue[0], qcount + per_depth, seg_size, ctx->d_counters);
+                               ctx->d_world, first, cnt, seeds, staging, queue[0], qcount + per_depth, seg_size, ctx->d_counters);
             for (int d = 1; d <= ctx->itr_limit - 1; d++) {          // a path is at most itr_limit - 1 rays long
                 PathRec *qin = queue[(d - 1) & 1], *qout = queue[d & 1];
                 if (ctx->detailed)
@@ -2275,7 +2307,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
                     hipLaunchKernelGGL((k_wf_extend<false>), dim3(ctx->num_cus), dim3(threads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted,
                                        levels, qin, qcount + d * per_depth, seg_size, hits, qhead + d * per_depth, ctx->d_counters, wt);
                 hipLaunchKernelGGL(k_wf_shade, sgrid, dim3(256), 0, ctx->stream, sv, qin, hits, qcount + d * per_depth, qout,
-                                   qcount + (d + 1) * per_depth, seg_size, ctx->d_samples, first, cnt, ctx->itr_limit);
+                                   qcount + (d + 1) * per_depth, seg_size, staging, first, cnt, ctx->itr_limit);
             }
             if (ev_end) PT_HIP(ctx, hipEventRecord(ev_end, ctx->stream));
             PT_HIP(ctx, hipGetLastError());
@@ -2299,7 +2331,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             int frame_lanes_log2 = 0;                    // lanes per pixel: the largest power of two <= count, at most 256
             while (frame_lanes_log2 < 8 && (2u << frame_lanes_log2) <= cnt) frame_lanes_log2++;
             hipLaunchKernelGGL(k_path_seeds, dim3((unsigned)ctx->num_cus * 16u), dim3(256), 0, ctx->stream, ctx->W, (unsigned)npix, cnt,
-                               seeds, ctx->d_samples, frame_lanes_log2);
+                               seeds, staging, frame_lanes_log2);
             // A tree in LDS leaves stack room for `threads` lanes; the waves up to 1024 threads (scene04: one, the sixteenth)
             // run too, with their stack entries in global memory: 115 -> 109 ms per 128 frames of scene04.
             int xthreads = (lds_nodes && !kn.max_threads) ? 1024 - threads : 0;       // (PTAMD_MAX_THREADS asks for FEWER waves)
@@ -2320,7 +2352,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream)); \
             hipLaunchKernelGGL((k_trace_persistent<C, L, N, P, G>), dim3(ctx->num_cus), dim3(threads + ((L) ? xthreads : 0)), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
                 ctx->d_gstack, n_slots, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, seeds, \
-                ctx->d_samples, ctx->d_counters, ctx->d_work, \
+                staging, ctx->d_counters, ctx->d_work, \
                 order, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, \
                 (uint32_t)chunk, tune, top, threads, xstack); } while (0)
             // slot of the variant in ctx->lds_attr: COUNT, LDSN, NEAR as bits; + 10 with pair lines, + 16 / + 22 for trees with
@@ -2345,7 +2377,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
                 if (int rc_ = ensure_lds_limit(ctx, SLOT, &k_trace_dual<C, L>, lds_bytes)) return rc_; \
                 if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream)); \
                 hipLaunchKernelGGL((k_trace_dual<C, L>), dim3(ctx->num_cus), dim3(threads + xthreads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
-                    n_slots, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, ctx->d_samples, ctx->d_counters, ctx->d_work, \
+                    n_slots, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, staging, ctx->d_counters, ctx->d_work, \
                     order, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, (uint32_t)chunk, dt, top, threads, xstack); } while (0)
                 if (lds_nodes) { if (ctx->detailed) PT_LAUNCH_DUAL(31, true, true); else PT_LAUNCH_DUAL(30, false, true); }
                 else           { if (ctx->detailed) PT_LAUNCH_DUAL(19, true, false); else PT_LAUNCH_DUAL(18, false, false); }
@@ -2377,9 +2409,9 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             pt_context::PipeSlot &other = ctx->pipe[ctx->pipe_active ^ 1];
             if (other.used) PT_HIP(ctx, hipStreamWaitEvent(ctx->stream, other.done, 0));
         }
-        if (lin) hipLaunchKernelGGL(k_accumulate<true>, agrid, dim3(256), 0, ctx->stream, ctx->d_samples, npix, first, cnt,
+        if (lin) hipLaunchKernelGGL(k_accumulate<true>, agrid, dim3(256), 0, ctx->stream, staging.rgb, npix, first, cnt,
                                     ctx->d_output, ctx->d_display, ctx->d_linear, ctx->W, reg);
-        else     hipLaunchKernelGGL(k_accumulate<false>, agrid, dim3(256), 0, ctx->stream, ctx->d_samples, npix, first, cnt,
+        else     hipLaunchKernelGGL(k_accumulate<false>, agrid, dim3(256), 0, ctx->stream, staging.rgb, npix, first, cnt,
                                     ctx->d_output, ctx->d_display, ctx->d_linear, ctx->W, reg);
         PT_HIP(ctx, hipGetLastError());
     }

@@ -74,6 +74,7 @@ int pth_tracer_frame_count(const RayTracer *r) { return r->frame_count; }
 void pth_tracer_set_frame_count(RayTracer *r, int v) { r->frame_count = v; }
 int pth_tracer_resize(RayTracer *r, int w, int h) { r->resize(w, h); return r->ok() ? 0 : -1; }
 void pth_tracer_set_tiles(RayTracer *r, int tx, int ty) { r->tiles_x = tx; r->tiles_y = ty; }
+void pth_tracer_set_tile_seed_per_dispatch(RayTracer *r, int on) { r->tile_seed_per_dispatch = on != 0; }
 void pth_tracer_set_build_flags(RayTracer *r, unsigned flags) { r->build_flags = flags; }
 int pth_tracer_rebuild(RayTracer *r) { r->buildRadixTree(); return r->ok() ? 0 : -1; }
 int pth_tracer_members(RayTracer *r, pt_Bound *bb, pt_PrimitiveRay *sorted_rays, pt_TreeNode *tree)

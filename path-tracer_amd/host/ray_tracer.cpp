@@ -161,16 +161,19 @@ void RayTracer::trace()
 {
     if (!ctx_) return;
     if (!gbuffer_ready_) renderGBuffer();
-    uint32_t seed;
-    if (use_random_device) {
-        // 16 draws per frame, the first one is used (ray_tracer.cpp:315-318)
-        static std::random_device rd;
-        static std::uniform_int_distribution<uint32_t> dist(0, 0xFFFFFFFF);
-        seed = dist(rd);
-        for (int i = 1; i < 16; i++) (void)dist(rd);
-    } else {
-        pt_frame_seeds(base_seed, (uint32_t)frame_count, 1, &seed);
-    }
+    // seed of dispatch number `dispatch`: 16 draws, the first one is used (ray_tracer.cpp:315-318)
+    auto draw_seed = [this](uint32_t dispatch) {
+        uint32_t s;
+        if (use_random_device) {
+            static std::random_device rd;
+            static std::uniform_int_distribution<uint32_t> dist(0, 0xFFFFFFFF);
+            s = dist(rd);
+            for (int i = 1; i < 16; i++) (void)dist(rd);
+        } else {
+            pt_frame_seeds(base_seed, dispatch, 1, &s);
+        }
+        return s;
+    };
     if (tiles_x > 1 || tiles_y > 1) {
         // ray_tracer.cpp:302-332: for (w = 0; w < width; w += width / TILEX) for (h = 0; h < height; h += height / TILEY),
         // offset = {w, h, w + width / TILEX - 1, h + height / TILEY - 1}.  As there, a width that TILEX does not
@@ -178,12 +181,19 @@ void RayTracer::trace()
         flush();
         const int tw = width / tiles_x, th = height / tiles_y;
         if (tw < 1 || th < 1) { error_ = "trace: more tiles than pixels"; return; }
+        const uint32_t per_frame = (uint32_t)((width + tw - 1) / tw) * (uint32_t)((height + th - 1) / th);
+        uint32_t tile = 0;
+        uint32_t seed = tile_seed_per_dispatch ? 0u : draw_seed((uint32_t)frame_count);
         for (int w = 0; w < width; w += tw)
-            for (int h = 0; h < height; h += th)
+            for (int h = 0; h < height; h += th) {
+                if (tile_seed_per_dispatch) seed = draw_seed((uint32_t)frame_count * per_frame + tile);
+                tile++;
                 if (!check(pt_trace_region(ctx_, (uint32_t)frame_count, seed, w, h, w + tw - 1, h + th - 1), "pt_trace_region")) return;
+            }
         frame_count += 1;
         return;
     }
+    const uint32_t seed = draw_seed((uint32_t)frame_count);
     // a caller that moved frame_count (the reference's ACC toggle sets it to 0) starts a new batch
     if (!pending_seeds_.empty() && frame_count != pending_first_ + (int)pending_seeds_.size()) flush();
     if (pending_seeds_.empty()) pending_first_ = frame_count;

@@ -79,15 +79,20 @@ public:
     int frames_per_launch = 32;
     void flush();
     // flags handed to pt_build by loadScene() and buildRadixTree().  PT_BUILD_DEFAULT builds the
-    // reference's tree (radix_tree_build.hlsl:25-137); PT_BUILD_MORTON_FULL / PT_BUILD_TOPOLOGY_MORTON
+    // reference's tree (radix_build_cs.hlsl:30-96, bvh_build_cs.hlsl:17-55); PT_BUILD_MORTON_FULL / PT_BUILD_TOPOLOGY_MORTON
     // are the labelled non-parity options for large scenes.  Set before loadScene().
     unsigned build_flags = PT_BUILD_DEFAULT;
     // the reference's TILEX / TILEY (ray_tracer.cpp:298-299, compiled as 1): the image is traced in
     // tiles_x * tiles_y dispatches per frame, each over width / tiles_x by height / tiles_y pixels with
-    // the offset and inclusive bounds of ray_tracer.cpp:319-322.  The reference draws a new seed per
-    // tile; here every tile of a frame uses the frame's seed, so the image does not depend on the tiling.
-    // Values above 1 launch inside run() (frames are not batched).
+    // the offset and inclusive bounds of ray_tracer.cpp:319-322.  Values above 1 launch inside run()
+    // (frames are not batched).
     int tiles_x = 1, tiles_y = 1;
+    // The reference fills random[] inside the tile loop (ray_tracer.cpp:315-318): a new seed per DISPATCH, 16
+    // draws each.  false (default): every tile of a frame uses the frame's seed, so the image does not depend
+    // on the tiling.  true: the reference's literal behaviour -- dispatch number d (counted over all frames,
+    // tiles of a frame in loop order) uses output 16*d of mt19937(base_seed), or 16 fresh draws of
+    // random_device; with one tile per frame the two settings are the same.
+    bool tile_seed_per_dispatch = false;
     float eye[3] = {0.0f, 5.0f, 23.0f};                 // CS.cpp:49
     float at[3] = {0.0f, 5.0f, 0.0f};                   // CS.cpp:50
     // material constants + eye into CB_Radix (reference: CS.cpp:405-439)

@@ -6,7 +6,12 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
 run() {  # name, counters...
   local name=$1; shift
-  timeout -s KILL 170 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/scripts/pmc_target.py $ARGS > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -3 $OUT/$name.log; return 1; }
+  # (a line a minute while the pass runs: the pass itself prints only at its end)
+  ( while sleep 50; do echo "  pass $name of $ARGS running"; done ) & local hb=$!
+  timeout -s KILL 280 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/scripts/pmc_target.py $ARGS > $OUT/$name.log 2>&1
+  local rc=$?
+  kill $hb 2> /dev/null; wait $hb 2> /dev/null
+  if [ $rc -ne 0 ]; then echo "pass $name failed"; tail -3 $OUT/$name.log; return 1; fi
   echo "pass $name ok"
 }
 ARGS="$*"

@@ -1,5 +1,7 @@
 """Small torch-free target for rocprofv3 counter passes:
-  trace            scene04 1162x1008, 3 launches of 128 frames (the benchmark's step)
+  trace [scene W H]  scene04 1162x1008 (or the named scene and size), 3 launches of 128 frames (the benchmark's step)
+  soup100m [index|morton] [near]   the benchmark's largest configuration (bench.py --config soup100m: 100M triangles generated
+                   on the device, 3840x2160, 3 launches of 2 frames), set up by bench.py's own function
   build [n]        n-triangle soup (default 10M), 3 tree-only builds and 3 default builds
   soup [n] [near] [morton]  n-triangle soup (default 10M) rendered with the options of the largest configuration
                    (full-resolution codes, deep stack, at most 8 rays per path, node records in global memory; near: nearest
@@ -13,14 +15,24 @@ from bench import soup
 mode = sys.argv[1]
 ctx = ptamd.Context(0)
 if mode == "trace":
-    g = np.load(os.path.join(ROOT, "tests", "golden", "scene04.npz"))
+    scene = sys.argv[2] if len(sys.argv) > 2 else "scene04"
+    W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1162, 1008)
+    g = np.load(os.path.join(ROOT, "tests", "golden", scene + ".npz"))
     ctx.upload_primitives(g["prims"].view(ptamd.PRIM_RENDER)); ctx.set_constants(g["cb"].view(ptamd.CB_RADIX))
-    ctx.build(); ctx.resize(1162, 1008)
+    ctx.build(); ctx.resize(W, H)
     ctx.primary_hits(ptamd.default_camera(), ptamd.albedo_table(g["mat_table"][:, 0:3], True))
     for s in range(3):
         ctx.trace_frames(128 * s, ptamd.frame_seeds(1, 128 * s, 128), ptamd.PT_ACCUM_LINEAR)
     ctx.synchronize()
     print(ctx.counters())
+elif mode == "soup100m":
+    from bench import setup_soup_scene
+    topology = "morton" if "morton" in sys.argv[2:] else "index"
+    keep, cb, _ = setup_soup_scene(ctx, 100_000_000, 3840, 2160, topology, "near" in sys.argv[2:])
+    ctx.set_trace_timing(True)
+    for s in range(3):
+        ctx.trace_frames(2 * s, ptamd.frame_seeds(1, 2 * s, 2), ptamd.PT_ACCUM_LINEAR)
+    print("trace ms", ctx.trace_times(), ctx.counters())
 elif mode == "soup":
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
     near = "near" in sys.argv[3:]

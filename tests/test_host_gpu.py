@@ -133,6 +133,20 @@ def test_raytracer_resize_acc_toggle_and_tiles(golden, monkeypatch):
             old, outu, _, _ = orc.trace_frame(sc, gb, f, seeds[f], old)
         out, disp = _read(L, r, W, H)
         assert out.tobytes() == old.tobytes() and np.array_equal(disp, outu)
+        # the reference's literal seeding: a new seed per DISPATCH of the tile loop (ray_tracer.cpp:315-318).  Frame 3 is
+        # dispatches 3 * 8 .. 3 * 8 + 7 (4 columns x 2 rows, columns outermost); a tile's pixels are those of a whole frame
+        # traced with the tile's seed
+        L.pth_tracer_set_tile_seed_per_dispatch.argtypes = [C.c_void_p, C.c_int]
+        L.pth_tracer_set_tile_seed_per_dispatch(r, 1)
+        assert L.pth_tracer_run(r, 1) == 4, L.pth_tracer_error(r)
+        tw, th = W // 3, H // 2
+        new, t = old.copy(), 0
+        for w in range(0, W, tw):
+            for h in range(0, H, th):
+                full = orc.trace_frame(sc, gb, 3, orc.frame_seeds(1, 3 * 8 + t, 1)[0], old)[0]
+                new[h:h + th, w:w + tw] = full[h:h + th, w:w + tw]
+                t += 1
+        assert t == 8 and _read(L, r, W, H)[0].tobytes() == new.tobytes()
     finally:
         L.pth_tracer_free(r)
 

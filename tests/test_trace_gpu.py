@@ -533,6 +533,21 @@ SNAPSHOT_EYE = (0.0032, 4.9588, 23.6159)
 SNAPSHOT_AT = (0.0005, 4.9987, 0.1000)
 
 
+# Rectangles of the snapshot that each exercise one part of the shading code, with the largest channel-mean difference
+# (8-bit levels) accepted at 4096 frames: about twice what is measured (0.27, 0.33, 0.11, 0.12, 0.10, 0.34, 0.03, 1.0;
+# the light's rim is antialiased by the reference's rasteriser and glows into the clipped range).
+SNAPSHOT_REGIONS = (
+    ("mirror sphere (Phong lobe, ns = 1000)", (330, 690, 470, 830), 0.6),
+    ("glass sphere (dielectric branch)", (700, 720, 850, 880), 0.7),
+    ("red wall (diffuse, first-hit albedo bytes)", (30, 250, 170, 750), 0.3),
+    ("blue wall (diffuse)", (1000, 250, 1130, 750), 0.3),
+    ("back wall (diffuse, indirect light only)", (300, 250, 860, 600), 0.3),
+    ("floor with the glass sphere's caustic", (640, 900, 960, 990), 0.7),
+    ("ceiling beside the light", (250, 20, 450, 150), 0.15),
+    ("light and its rim (emissive first hit, clipped)", (470, 70, 700, 145), 2.0),
+)
+
+
 def test_converged_image_close_to_reference_snapshot(gpu_ctx_factory, golden):
     """scene01 at 1162x1008 against the reference's one shipped output (24440 frames, unknown seeds,
     rasterised primaries), rendered from the fitted camera pose.  Image-level agreement of the whole
@@ -570,6 +585,12 @@ def test_converged_image_close_to_reference_snapshot(gpu_ctx_factory, golden):
         if quirk:
             assert rmse < 5.5
             assert rmse8 < 1.0
+            # region by region, so that a change in ONE branch of the material code cannot hide inside the global figures:
+            # channel means over fixed pixel rectangles (x0, y0, x1, y1), in 8-bit levels
+            for name, (x0, y0, x1, y1), tol in SNAPSHOT_REGIONS:
+                d = np.abs(img[y0:y1, x0:x1].mean(axis=(0, 1)) - ref[y0:y1, x0:x1].mean(axis=(0, 1)))
+                print("  region", name, "channel mean diff", d)
+                assert d.max() < tol, (name, d)
     assert means[True].max() < 0.3
     assert means[False].min() > 3.0
 

@@ -72,6 +72,37 @@ def test_noalloc_build_edge_sizes(gpu_ctx_factory, n):
     _same_tree(tree, e_tree)
 
 
+def test_noalloc_build_leaves_the_free_device_memory_unchanged(gpu_ctx_factory):
+    """hipMemGetInfo before and after: calls of the entry point take no device memory (nothing allocated, nothing
+    freed), at two sizes and with the codes on and off.  The first call of a process is made before the measurement: the
+    HIP runtime loads a library's code objects into device memory when its first kernel is launched."""
+    ctx = gpu_ctx_factory()
+    dev = torch.device("cuda", 0)
+    sizes = (50_000, 3_000)
+    bufs = []
+    for n in sizes:
+        prims = make_soup(n, seed=n, dtype=ptamd.PRIM_RENDER)
+        bufs.append((n, torch.from_numpy(np.ascontiguousarray(prims).view(np.uint8).reshape(-1)).to(dev),
+                     torch.empty((n,), dtype=torch.int64, device=dev), torch.empty((n,), dtype=torch.int32, device=dev),
+                     torch.empty((2 * n * 12,), dtype=torch.int32, device=dev)))
+    n, p, c, m, t = bufs[0]
+    ctx.build_tree_noalloc(p.data_ptr(), n, c.data_ptr(), m.data_ptr(), t.data_ptr(), ptamd.PT_BUILD_KARRAS_LINKS)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    free_before, total = torch.cuda.mem_get_info(dev)
+    for rep in range(3):
+        for n, p, c, m, t in bufs:
+            ctx.build_tree_noalloc(p.data_ptr(), n, c.data_ptr() if rep % 2 == 0 else 0, m.data_ptr(), t.data_ptr(),
+                                   ptamd.PT_BUILD_KARRAS_LINKS if rep == 1 else 0)
+            # (no synchronisation inside the loop either: a caller under graph capture could not make one)
+    free_enqueued, _ = torch.cuda.mem_get_info(dev)
+    ctx.synchronize()
+    free_after, _ = torch.cuda.mem_get_info(dev)
+    assert free_before == free_enqueued == free_after, (free_before, free_enqueued, free_after)
+    perm = bufs[1][3].cpu().numpy()
+    assert np.array_equal(np.sort(perm), np.arange(sizes[1]))       # and the calls did their work
+
+
 @pytest.mark.parametrize("scene", SCENES)
 def test_noalloc_build_reference_scenes(gpu_ctx_factory, golden, scene):
     g = golden[scene]
