@@ -6,7 +6,8 @@
 #            one rocprofv3 --pmc run per counter group (scripts/pmc_run.sh)
 #   pmc4k    r03_trace_scene02_4k_pmc.json, r03_trace_scene03_4k_pmc.json: the same for scene02 / scene03 at 3840x2160
 #   pmc100m  r03_soup100m_pmc.json, r03_soup100m_near_first_pmc.json, r03_soup100m_morton_pmc.json: the same for the
-#            largest configuration (reference's tree in both traversal orders; tree over the codes, nearest child first)
+#            largest configuration (reference's tree in both traversal orders; tree over the codes, nearest child first);
+#            pmc100m_index / pmc100m_near / pmc100m_morton: one of the three
 #   bench    r03_bench_default.json + r03_bench_default_kernel_stats.csv (python bench.py under rocprofv3 --kernel-trace --stats),
 #            r03_bench_scene0{2,3}_4k.json, r03_bench_soup100m*.json, r03_random_records.txt
 # bench.py reads the counter summaries from profiles/: run the pmc parts first and copy their files there.
@@ -36,6 +37,9 @@ pmc100m)
   pmc soup100m_near_first soup100m index near
   pmc soup100m_morton soup100m morton near
   ;;
+pmc100m_index) pmc soup100m soup100m index ;;
+pmc100m_near) pmc soup100m_near_first soup100m index near ;;
+pmc100m_morton) pmc soup100m_morton soup100m morton near ;;
 bench)
   cd /tmp && rm -rf /tmp/kstats
   timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kstats -- python3 $R/bench.py > $O/r03_bench_default.json 2> $O/bench_default.err || { tail -5 $O/bench_default.err; exit 1; }

@@ -11,7 +11,9 @@ for f in glob.glob(os.path.join(src, "*", "**", "*counter_collection.csv"), recu
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
         m = re.search(r"(k_\w+)", name)
-        k = m.group(1) if m else name.replace("void ", "").split("(")[0].strip()
+        if not m:
+            continue                # kernels of other libraries (the device-side scene generator of the largest configuration)
+        k = m.group(1)
         if k in ("k_trace_persistent", "k_trace_dual", "k_wf_extend") and (k + "<true") in name:
             k += "<detailed>"
         if k == "k_refit_low" and "k_refit_low<true" in name:

@@ -10,9 +10,13 @@ import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd")); sys.path.insert(0, ROOT)
+mode = sys.argv[1]
+if mode == "soup100m":
+    # the soup is generated on the device by torch: torch first, so that the library binds to the HIP runtime torch brings
+    # (as in bench.py); the other modes stay torch-free
+    import torch  # noqa: F401
 import ptamd
 from bench import soup
-mode = sys.argv[1]
 ctx = ptamd.Context(0)
 if mode == "trace":
     scene = sys.argv[2] if len(sys.argv) > 2 else "scene04"
