@@ -50,6 +50,9 @@ static void read_knobs(Knobs &k)
     k.fine_frac = env_int("PTAMD_FINE_FRAC", k.fine_frac, 0, 1 << 20);
     k.fine_chunk = env_int("PTAMD_FINE_CHUNK", k.fine_chunk, 0, 1 << 20);
     k.extra_wave = env_int("PTAMD_EXTRA_WAVES", k.extra_wave, 0, 16);      // a workgroup has at most 16 waves
+    k.pipe_slots = env_int("PTAMD_PIPE_SLOTS", k.pipe_slots, 2, PT_PIPE_SLOTS_MAX);
+    k.short_grid_div = env_int("PTAMD_SHORT_GRID_DIV", k.short_grid_div, 0, 8);
+    k.short_grid = env_int("PTAMD_SHORT_GRID", k.short_grid, 0, 4096);
 }
 
 static int bit_length_u(unsigned v) { return v ? 32 - __builtin_clz(v) : 0; }
@@ -637,7 +640,7 @@ static int trace_frames(pt_context *ctx, const char *who, uint32_t first_frame, 
             for (auto &any : ctx->pipe) if (any.stream) PT_HIP(ctx, hipStreamWaitEvent(any.stream, ctx->pipe_fork, 0));
             ctx->main_dirty = false;
         }
-        ctx->pipe_next = i ^ 1;
+        ctx->pipe_next = (i + 1) % ctx->knobs.pipe_slots;
         ctx->pipe_active = i;
     }
     Swap swap(ctx, sl);

@@ -66,6 +66,8 @@ constexpr int PT_REFIT_CHUNK_LOG2 = 10;
 constexpr int PT_REFIT_CHUNK = 1 << PT_REFIT_CHUNK_LOG2;        // 1024 sorted keys per workgroup
 
 constexpr int PT_SEED_SLOTS = 4;
+// most internal streams that short trace calls are spread over (see pt_context::PipeSlot)
+constexpr int PT_PIPE_SLOTS_MAX = 4;
 // highest Morton-keyed tree the traversal stacks are sized for (PT_BUILD_TOPOLOGY_MORTON)
 constexpr int PT_MAX_TREE_HEIGHT = 64;
 // size of the library's static scratch array (pt_build_tree_noalloc): what PT_NOALLOC_MAX_PRIMS needs
@@ -110,6 +112,12 @@ struct Knobs {
     int extra_wave = 16;                // PTAMD_EXTRA_WAVES: most waves per CU that k_trace_dual runs beyond those whose stacks fit in LDS beside the tree (their stacks: global memory); 0: none
     int fine_frac = 4, fine_chunk = 8;  // PTAMD_FINE_FRAC / PTAMD_FINE_CHUNK: k_trace_dual hands out the last 1/fine_frac of a launch's frames in items of fine_chunk frames (0: off)
     int sort_chained = 1;               // PTAMD_SORT_CHAINED: sorts of more than two passes read their keys once per pass (0: separate counting pass per pass)
+    // Overlapped short calls, measured on scene04 with one frame per call (scripts/gpu_short_calls.py): three streams (with the
+    // context's own that makes the four hardware queues a process has; a fourth stream shares a queue and loses), each launch over
+    // 7/16 of the CUs, so that two launches fill the chip and the third takes the CUs the first one frees: 2.48 -> 3.33 Grays/s
+    int pipe_slots = 3;                 // PTAMD_PIPE_SLOTS: internal streams that overlapped short trace calls use in turn (2 .. PT_PIPE_SLOTS_MAX)
+    int short_grid = 0;                 // PTAMD_SHORT_GRID: workgroups of an overlapped short call's launch (0: 7/16 of the CUs, or by the divisor)
+    int short_grid_div = 0;             // PTAMD_SHORT_GRID_DIV: ... one workgroup per this many CUs (0: unset)
 };
 
 struct pt_context {
@@ -199,8 +207,10 @@ struct pt_context {
     uint32_t seeds_cap = 0;
 
     // Overlap of short consecutive trace calls (one frame per call is the reference's own run loop): such a call's seeds
-    // copy, seed, trace and accumulate kernels run on one of two internal streams, used in turn, with the buffers of that
-    // slot, so that the next call's paths fill the CUs that the previous call's last paths leave idle.  Accumulates are
+    // copy, seed, trace and accumulate kernels run on one of a few internal streams, used in turn, with the buffers of that
+    // slot, so that the next calls' paths fill the CUs that the previous calls' last paths leave idle (a kernel on a stream
+    // starts only when EVERY workgroup of the stream's previous kernel has ended, so each stream more lets one more
+    // call's workgroups take the CUs as they become free).  Accumulates are
     // chained through the slots' `done` events (the image recurrence), and the context's own stream waits for every
     // slot's `done` as soon as it is recorded, so everything else stays ordered with the context's stream as before.
     struct PipeSlot {
@@ -213,7 +223,7 @@ struct pt_context {
         uint32_t *d_seeds = nullptr;
         uint32_t seeds_cap = 0;
     };
-    PipeSlot pipe[2];
+    PipeSlot pipe[PT_PIPE_SLOTS_MAX];  // knobs.pipe_slots of them are used
     hipEvent_t pipe_fork = nullptr;
     int pipe_next = 0;                // slot of the next overlapped call
     int pipe_active = -1;             // slot whose buffers are swapped into the context while a call is enqueued

@@ -23,6 +23,7 @@
 // children on a per-lane LDS stack.
 #include "pt_internal.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -2314,7 +2315,13 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
         } else {
             // frames per work item: about 16 items per lane, so that the launch ends on short
             // items, in equal parts of the launch's frames
-            const unsigned long long lanes = (unsigned long long)ctx->num_cus * threads;
+            // overlapped short calls: several launches are in flight, each may take a part of the CUs
+            unsigned grid = (unsigned)ctx->num_cus;
+            if (ctx->pipe_active >= 0) {
+                int g = kn.short_grid > 0 ? kn.short_grid : (kn.short_grid_div > 0 ? ctx->num_cus / kn.short_grid_div : ctx->num_cus * 7 / 16);
+                grid = (unsigned)std::max(1, std::min(g, ctx->num_cus));
+            }
+            const unsigned long long lanes = (unsigned long long)grid * threads;
             unsigned long long chunk = ((unsigned long long)cnt * n_slots) / (lanes * 16ull);
             if (chunk < 1) chunk = 1;
             if (chunk > cnt) chunk = cnt;
@@ -2338,10 +2345,10 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             if (xthreads > 64 * kn.extra_wave) xthreads = 64 * kn.extra_wave;
             // 16 waves x 32 levels x 64 lanes per CU cover every case of ONE launch; launches of overlapped short calls run
             // side by side (workgroup b of the next call starts on a CU while workgroup b of this one is still in its
-            // tail), so the context's stream and each of the two overlap slots get a region of their own
+            // tail), so the context's stream and each of the overlap slots get a region of their own
             const size_t xstack_region = (size_t)ctx->num_cus * 16 * 32 * 64;
             if (xthreads && !ctx->d_xstack)
-                PT_HIP(ctx, hipMalloc((void **)&ctx->d_xstack, 3 * xstack_region * sizeof(float)));
+                PT_HIP(ctx, hipMalloc((void **)&ctx->d_xstack, (PT_PIPE_SLOTS_MAX + 1) * xstack_region * sizeof(float)));
             float *const xstack = ctx->d_xstack ? ctx->d_xstack + (size_t)(ctx->pipe_active + 1) * xstack_region : nullptr;
 #define PT_LAUNCH(SLOT, C, L, N) PT_LAUNCH_(SLOT, C, L, N, false, false)
 #define PT_LAUNCH_G(SLOT, C, N) do { \
@@ -2350,7 +2357,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
 #define PT_LAUNCH_(SLOT, C, L, N, P, G) do { \
             if (int rc_ = ensure_lds_limit(ctx, SLOT, &k_trace_persistent<C, L, N, P, G>, lds_bytes)) return rc_; \
             if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream)); \
-            hipLaunchKernelGGL((k_trace_persistent<C, L, N, P, G>), dim3(ctx->num_cus), dim3(threads + ((L) ? xthreads : 0)), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
+            hipLaunchKernelGGL((k_trace_persistent<C, L, N, P, G>), dim3(grid), dim3(threads + ((L) ? xthreads : 0)), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
                 ctx->d_gstack, n_slots, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, seeds, \
                 staging, ctx->d_counters, ctx->d_work, \
                 order, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, \
@@ -2376,7 +2383,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
 #define PT_LAUNCH_DUAL(SLOT, C, L) do { \
                 if (int rc_ = ensure_lds_limit(ctx, SLOT, &k_trace_dual<C, L>, lds_bytes)) return rc_; \
                 if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream)); \
-                hipLaunchKernelGGL((k_trace_dual<C, L>), dim3(ctx->num_cus), dim3(threads + xthreads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
+                hipLaunchKernelGGL((k_trace_dual<C, L>), dim3(grid), dim3(threads + xthreads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
                     n_slots, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, staging, ctx->d_counters, ctx->d_work, \
                     order, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, (uint32_t)chunk, dt, top, threads, xstack); } while (0)
                 if (lds_nodes) { if (ctx->detailed) PT_LAUNCH_DUAL(31, true, true); else PT_LAUNCH_DUAL(30, false, true); }
@@ -2406,7 +2413,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
         const dim3 agrid((unsigned)((npix + 255) / 256));
         if (ctx->pipe_active >= 0) {
             // the images are a recurrence over the calls: this call's accumulate follows the other slot's
-            pt_context::PipeSlot &other = ctx->pipe[ctx->pipe_active ^ 1];
+            pt_context::PipeSlot &other = ctx->pipe[(ctx->pipe_active + kn.pipe_slots - 1) % kn.pipe_slots];
             if (other.used) PT_HIP(ctx, hipStreamWaitEvent(ctx->stream, other.done, 0));
         }
         if (lin) hipLaunchKernelGGL(k_accumulate<true>, agrid, dim3(256), 0, ctx->stream, staging.rgb, npix, first, cnt,
