@@ -185,7 +185,7 @@ struct pt_context {
     // traversal iterations of earlier launches) and the pixels sorted by it
     uint32_t *d_cost = nullptr;       // W*H
     uint32_t *d_pixel_work = nullptr; // W*H, iterations of the current launch
-    float4 *d_samples = nullptr;      // staging of one launch, 16 bytes per path: [W*H][frames] x 3 floats of radiance, then [W*H][frames] path seeds
+    float4 *d_samples = nullptr;      // staging of one launch: [W*H][frames] slots of 16 bytes (a path's seed in .w, then its radiance sample)
     uint32_t samples_frames = 0;
     size_t samples_cap_bytes = 0;     // upper bound of the staging buffer: an eighth of the device's memory
     // wavefront trace: two path queues (48-byte records), hit records (16 bytes), queue lengths

