@@ -266,13 +266,23 @@ def bench_build(ctx_factory, n, reps, on_device, copy_gbs):
 
 
 def cpu_model():
+    """Model name of the host CPU as /proc/cpuinfo gives it, with family / model / stepping: the GPU boxes are virtual
+    machines whose model name carries no model number ("AMD EPYC"), the numbers still tell the generation."""
+    info = {}
     try:
         for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
+            k, _, v = line.partition(":")
+            k = k.strip()
+            if k in ("model name", "cpu family", "model", "stepping") and k not in info:
+                info[k] = v.strip()
+            if len(info) == 4:
+                break
     except Exception:
         pass
-    return "unknown"
+    if "model name" not in info:
+        return "unknown"
+    ids = ", ".join(f"{k} {info[k]}" for k in ("cpu family", "model", "stepping") if k in info)
+    return info["model name"] + (f" ({ids})" if ids else "")
 
 
 def cpu_baseline(g, W, H, budget_s=10.0, max_frames=32):

@@ -1,5 +1,5 @@
 """CPU: the benchmark's output contract, checked on the committed record of the last GPU run
-(profiles/r02_bench_default.json) and on bench.py's command line."""
+(profiles/r03_bench_default.json) and on bench.py's command line."""
 import json
 import os
 import subprocess
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_every_contract_field():
-    line = open(os.path.join(ROOT, "profiles", "r02_bench_default.json")).read().strip().splitlines()[-1]
+    line = open(os.path.join(ROOT, "profiles", "r03_bench_default.json")).read().strip().splitlines()[-1]
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -54,15 +54,43 @@ def test_kernel_stats_agree_with_the_bench_line():
     """The profiler's average duration of the trace kernel and the HIP-event time inside bench.py
     come from the same run and must agree."""
     import csv
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_default.json")).read().strip().splitlines()[-1])
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_default.json")).read().strip().splitlines()[-1])
     avg, total = None, 0.0
-    for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_bench_default_kernel_stats.csv"))):
+    for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r03_bench_default_kernel_stats.csv"))):
         # the variant the benchmark's steps run: the uninstrumented one (first template argument false) of the kernel the
         # line names; of several matching rows (other variants ran once for the statistics block) the one that took the most time
         if (d["roofline"]["kernel"] + "<false") in r["Name"] and float(r["TotalDurationNs"]) > total:
             total, avg = float(r["TotalDurationNs"]), float(r["AverageNs"]) * 1e-6
     assert avg is not None
     assert abs(avg - d["roofline"]["launch_ms_avg"]) < 0.01 * avg
+
+
+def test_every_committed_bench_line_has_a_counter_backed_roofline():
+    """The lines of the other named configurations (3840x2160 scenes, the 100M-triangle soup): no null in the roofline,
+    and each figure recomputes from the counter summary the line names and the launch time in the line."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_bench_*.json")))
+    assert len(files) >= 6
+    for f in files:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        r = d["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert r.get(k) is not None, (f, k)
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] <= 1
+        assert r["profile"]["taken_with_these_kernel_sources"] is True
+        assert r["profile"]["meta"]["sources_sha256_16"] == d["kernel_sources_sha256_16"]
+        pmc = json.load(open(os.path.join(ROOT, r["profile"]["file"])))
+        if r["bound"] == "valu":
+            k = pmc[r["kernel"]]
+            assert abs(r["achieved"] - k["SQ_INSTS_VALU"] / (r["launch_ms_avg"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+        else:
+            # trees far larger than the caches: memory-side read requests per second against the best rate of dependent
+            # random record reads; the algorithmic 36 B per visit stays in the line as a labelled figure
+            assert r["bound"] == "memory requests" and "soup100m" in f
+            k = pmc["k_trace_persistent"]
+            assert abs(r["achieved"] - k["TCC_EA0_RDREQ_sum"] / (r["launch_ms_avg"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+            assert r["algorithmic_GBps"] > 0 and r["uniform_random_rate_at_tree_size"] < r["peak"]
+        assert abs(r["traffic"] - k["hbm_bytes_per_launch"]) < 1
 
 
 def test_bench_command_line():
