@@ -489,8 +489,7 @@ __device__ __forceinline__ void persistent_paths(const SceneView sc, const TriIs
     ray.o = hit_pos; ray.d = pt_mk3(0, 0, 1); ray.t_min = PT_EPSILON; ray.t_max = 10000;
     pt_f3 inv = pt_mk3(1, 1, 1);
     float current_t = 0;
-    bool intersected = false;
-    int hit_leaf = 0;
+    int hit_leaf = -1;                  // leaf key of the nearest hit so far, -1: none (see dual_paths)
     float hit_bx = 0, hit_by = 0, hit_bz = 0;
     // global-memory variant with child lines (PAIR): the 128-byte line of a node holds the records of BOTH its children
     // (the node's own record follows from them), so the node AND whichever child is visited next are expanded from one
@@ -576,7 +575,7 @@ __device__ __forceinline__ void persistent_paths(const SceneView sc, const TriIs
                     if (path_active) {
                         // back from intersect() (ray_tracing.hlsl:372-395)
                         bool ended = true;
-                        if (intersected) {
+                        if (hit_leaf >= 0) {
                             ray.o = pt_add3(ray.o, pt_scale3(ray.d, current_t));
                             itr++;
                             const float4 *shp = reinterpret_cast<const float4 *>(&sc.shade[hit_leaf]);
@@ -635,7 +634,7 @@ __device__ __forceinline__ void persistent_paths(const SceneView sc, const TriIs
                         ray.d = direction;
                         inv = pt_mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
                         current_t = ray.t_max;
-                        intersected = false;
+                        hit_leaf = -1;
                         pending = 0;
                         pend_left = 0;
                         cnt.rays++;
@@ -878,7 +877,6 @@ __device__ __forceinline__ void persistent_paths(const SceneView sc, const TriIs
                                 hit_bx = bx; hit_by = by; hit_bz = bz;
                                 current_t = t;
                                 hit_leaf = cur_s;          // the shading record is in leaf order too
-                                intersected = true;
                             }
                         }
                     }
@@ -1007,6 +1005,9 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
     const int STARVE_T = tune.refill_t, SHADE_T = tune.shade_t, LEAF_T = tune.leaf_t, ITR_LIMIT = tune.itr_limit, SWAP_T = tune.swap_t;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // the stack entry of level L sits (L - 1) rows above the lane's first one: one multiply-add on the byte address
+    const unsigned row_bytes = XW ? 64u * 4u : (unsigned)nthreads * 4u;
+    char *const stack_b = reinterpret_cast<char *>(XW ? xst : stack);
     // items: first every pixel's coarse chunks of the frames [0, coarse_frames), then every pixel's fine chunks of the rest
     const unsigned coarse_frames = count - (unsigned)tune.fine_frames, fine_chunk = (unsigned)tune.fine_chunk;
     const unsigned chunks = (coarse_frames + chunk - 1) / chunk;
@@ -1040,8 +1041,9 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
     unsigned pending = 0;
     pt_f3 ro = pt_mk3(0, 0, 0), rd = pt_mk3(0, 0, 1), inv = pt_mk3(1, 1, 1);
     float current_t = 0;
-    bool intersected = false;
-    int hit_leaf = 0;
+    // leaf key of the nearest hit so far, -1: none.  (A flag of its own would be a wave mask in a scalar register pair that the
+    // compiler patches at the end of every divergent branch of the loop: folded into the key, 105.2 -> 102.9 ms per 128 frames.)
+    int hit_leaf = -1;
     float hit_bx = 0, hit_by = 0;
     // parked slot.  p_q: P_READY: 1 / direction; P_DONE: {leaf key of the hit or -1 (bits), barycentric x, y}
     int p_state = P_NONE;
@@ -1056,15 +1058,15 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
     // whose parked slot holds a ray (`take`) or is free.
     auto exchange = [&](bool take) {
         const bool done = cur_k == K_IDLE;
-        if (done && intersected) ro = pt_add3(ro, pt_scale3(rd, current_t));
-        inv.x = __int_as_float(intersected ? hit_leaf : -1); inv.y = hit_bx; inv.z = hit_by;      // the outgoing p_q
+        if (done && hit_leaf >= 0) ro = pt_add3(ro, pt_scale3(rd, current_t));
+        inv.x = __int_as_float(hit_leaf); inv.y = hit_bx; inv.z = hit_by;      // the outgoing p_q
         lane_swap(ro.x, p_o.x); lane_swap(ro.y, p_o.y); lane_swap(ro.z, p_o.z);
         lane_swap(rd.x, p_d.x); lane_swap(rd.y, p_d.y); lane_swap(rd.z, p_d.z);
         lane_swap(inv.x, p_q0); lane_swap(inv.y, p_q1); lane_swap(inv.z, p_q2);
         act ^= 1;
         p_state = done ? P_DONE : (f < f_end ? P_START : P_NONE);
         if (take) {
-            current_t = T_MAX; intersected = false; pending = 0;
+            current_t = T_MAX; hit_leaf = -1; pending = 0;
             cur_k = levels; cur_s = 0; cur_id = 0;
         } else {
             cur_k = K_EMPTY;
@@ -1257,7 +1259,7 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
                     int km1 = k - 1, sr = cur_s + half;
                     const int e = min(sr + half - 1, n);
                     int kr = 32 - __clz(sr ^ e);
-                    float *const slot = XW ? xst + (k - 1) * 64 : stack + __umul24((unsigned)(k - 1), (unsigned)nthreads);
+                    float *const slot = reinterpret_cast<float *>(stack_b + __umul24((unsigned)(k - 1), row_bytes));
                     unsigned pend_both = pending | (1u << k);
                     asm volatile("" : "+v"(kr), "+v"(sr), "+v"(pend_both), "+v"(km1));
                     __builtin_amdgcn_sched_barrier(0);
@@ -1267,10 +1269,9 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
                     const bool hl = slab(lmn, lmx, ro, inv, tl) && tl <= current_t;
                     const bool hr = slab(rmn, rmx, ro, inv, tr) && tr <= current_t;
                     if (COUNT) { cnt.node_visits += 2; cnt.box_tests += 2; }
-                    if (hl && hr) {
-                        *slot = tr;
-                        pending = pend_both;
-                    }
+                    // (the entry is written whether or not both children pass: a row whose bit is not set is never read)
+                    *slot = tr;
+                    pending = (hl && hr) ? pend_both : pending;
                     cur_k = hl ? km1 : (hr ? kr : K_POP);
                     cur_id = hl ? sr - 1 : sr;
                     cur_s = hl ? cur_s : sr;
@@ -1278,25 +1279,25 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
         };
         auto pop = [&]() {
                 if (cur_k == K_POP) {
-                    if (pending == 0) {
-                        cur_k = K_IDLE;
-                    } else {
-                        const int L = __ffs((int)pending) - 1;
-                        const float t_entry = XW ? xst[(L - 1) * 64] : stack[__umul24((unsigned)(L - 1), (unsigned)nthreads)];
-                        __builtin_amdgcn_sched_barrier(0);
-                        pending &= pending - 1;
-                        const int sa = (cur_s >> L) << L, half = 1 << (L - 1);
-                        int sr = sa + half;
-                        const int e = min(sa + 2 * half - 1, n);
-                        int kp = 32 - __clz(sr ^ e);
-                        asm volatile("" : "+v"(kp), "+v"(sr), "+v"(pending));
-                        __builtin_amdgcn_sched_barrier(0);
-                        // an entry whose distance no longer passes the test is dropped and the lane tries again next time
-                        const bool take = t_entry <= current_t;
-                        cur_k = take ? kp : K_POP;
-                        cur_s = take ? sr : cur_s;
-                        cur_id = take ? sr : cur_id;
-                    }
+                    // no inner branch: a lane without a pending entry reads the root level's row (bit `levels` stands in for
+                    // a pending level) and only the final selects tell it apart
+                    const unsigned pend = pending | (1u << levels);
+                    const int L = __ffs((int)pend) - 1;
+                    const float t_entry = *reinterpret_cast<const float *>(stack_b + __umul24((unsigned)(L - 1), row_bytes));
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bool none = pending == 0;
+                    pending &= pending - 1;
+                    const int sa = (cur_s >> L) << L, half = 1 << (L - 1);
+                    int sr = sa + half;
+                    const int e = min(sa + 2 * half - 1, n);
+                    int kp = 32 - __clz(sr ^ e);
+                    asm volatile("" : "+v"(kp), "+v"(sr), "+v"(pending));
+                    __builtin_amdgcn_sched_barrier(0);
+                    // an entry whose distance no longer passes the test is dropped and the lane tries again next time
+                    const bool take = !none && t_entry <= current_t;
+                    cur_k = none ? K_IDLE : (take ? kp : K_POP);
+                    cur_s = take ? sr : cur_s;
+                    cur_id = take ? sr : cur_id;
                 }
         };
         for (;;) {
@@ -1327,7 +1328,8 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
                     const pt_f3 a = pt_mk3(t0.x, t0.y, t0.z), e_1 = pt_mk3(t1.x, t1.y, t1.z), e_2 = pt_mk3(t2.x, t2.y, t2.z);
                     const pt_f3 q = pt_cross3(rd, e_2);
                     const float a1 = pt_dot3(e_1, q);
-                    if (!(fabsf(a1) <= PT_EPSILON)) {
+                    {
+                        // (all lanes run the whole test; a determinant within epsilon only enters the final condition)
                         const pt_f3 oa = pt_sub3(ro, a);
                         const pt_f3 s = pt_mk3(oa.x / a1, oa.y / a1, oa.z / a1);
                         const pt_f3 r = pt_cross3(s, e_1);
@@ -1335,14 +1337,11 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
                         const float bx = pt_dot3(s, q);
                         const float by = pt_dot3(r, rd);
                         const float bz = 1 - bx - by;
-                        if (bx >= -PT_EPSILON && by >= -PT_EPSILON && bz >= -PT_EPSILON && t >= PT_EPSILON) {
-                            if (current_t > t && t > T_MIN) {
-                                hit_bx = bx; hit_by = by;
-                                current_t = t;
-                                hit_leaf = cur_s;
-                                intersected = true;
-                            }
-                        }
+                        const bool hit = !(fabsf(a1) <= PT_EPSILON) && bx >= -PT_EPSILON && by >= -PT_EPSILON && bz >= -PT_EPSILON &&
+                                         t >= PT_EPSILON && current_t > t && t > T_MIN;
+                        hit_bx = hit ? bx : hit_bx; hit_by = hit ? by : hit_by;
+                        current_t = hit ? t : current_t;
+                        hit_leaf = hit ? cur_s : hit_leaf;
                     }
                     cur_k = K_POP;
                 }
