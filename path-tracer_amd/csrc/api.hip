@@ -47,7 +47,8 @@ static void read_knobs(Knobs &k)
     k.shade_t = env_int("PTAMD_SHADE_T", k.shade_t, 1, 64);
     k.dual_leaf_t = env_int("PTAMD_DUAL_LEAF_T", k.dual_leaf_t, 1, 64);
     k.sort_chained = env_int("PTAMD_SORT_CHAINED", k.sort_chained, 0, 1);
-    k.fine_frac = env_int("PTAMD_FINE_FRAC", k.fine_frac, 0, 1 << 20);
+    k.fine_items = env_int("PTAMD_FINE_ITEMS", k.fine_items, 0, 1 << 20);
+    k.coarse_items = env_int("PTAMD_COARSE_ITEMS", k.coarse_items, 1, 1 << 20);
     k.fine_chunk = env_int("PTAMD_FINE_CHUNK", k.fine_chunk, 0, 1 << 20);
     k.extra_wave = env_int("PTAMD_EXTRA_WAVES", k.extra_wave, 0, 16);      // a workgroup has at most 16 waves
     k.pipe_slots = env_int("PTAMD_PIPE_SLOTS", k.pipe_slots, 2, PT_PIPE_SLOTS_MAX);

@@ -110,7 +110,8 @@ struct Knobs {
     int pair_min_mib = 24;              // PTAMD_PAIR_MIN_MIB: child lines only when the plain records take at least this much
     int pair_max_mib = 65536;           // PTAMD_PAIR_MAX_MIB: largest array of child lines (0: never use it)
     int extra_wave = 16;                // PTAMD_EXTRA_WAVES: most waves per CU that k_trace_dual runs beyond those whose stacks fit in LDS beside the tree (their stacks: global memory); 0: none
-    int fine_frac = 4, fine_chunk = 8;  // PTAMD_FINE_FRAC / PTAMD_FINE_CHUNK: k_trace_dual hands out the last 1/fine_frac of a launch's frames in items of fine_chunk frames (0: off)
+    int fine_items = 12, fine_chunk = 0; // PTAMD_FINE_ITEMS / PTAMD_FINE_CHUNK: k_trace_dual ends a launch on about fine_items short items per lane (0: none) of fine_chunk frames each (0: a sixteenth of the launch's frames, 2 .. 8)
+    int coarse_items = 4;               // PTAMD_COARSE_ITEMS: ... and hands the frames before those out in about this many long items per lane
     int sort_chained = 1;               // PTAMD_SORT_CHAINED: sorts of more than two passes read their keys once per pass (0: separate counting pass per pass)
     // Overlapped short calls, measured on scene04 with one frame per call (scripts/gpu_short_calls.py): three streams (with the
     // context's own that makes the four hardware queues a process has; a fourth stream shares a queue and loses), each launch over

@@ -2335,11 +2335,50 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             if (chunk > cnt) chunk = cnt;
             chunk = (cnt + (cnt + chunk - 1) / chunk - 1) / ((cnt + chunk - 1) / chunk);
             if (kn.chunk > 0) { chunk = (unsigned long long)kn.chunk; if (chunk > cnt) chunk = cnt; }
+            // two paths per lane need items of several frames (the two paths are two frames of one pixel): short launches,
+            // whose items are one or two frames, run the single-path kernel
+            const bool use_dual = (lds_nodes || (!gen && !use_pair)) && !near_first && kn.dual && chunk >= (unsigned long long)kn.dual_min_chunk;
+            // k_trace_dual hands a launch's frames out in two tiers.  An item's end costs (its last path runs without a second
+            // one to switch to, and the next item's pixel has to be fetched), so every pixel's first frames come in few long
+            // items, about kn.coarse_items per lane, which for an image of several pixels per lane is ONE item per pixel; the
+            // launch then ends on short items of the remaining frames, about kn.fine_items per lane (none when the long items are
+            // many per lane already).  Long items need the expensive pixels first: a launch without a cost order from its
+            // predecessors keeps the sixteen items per lane of the single-path kernel.  Measured on scene04, 32 / 128 frames per
+            // launch, against sixteen long items per lane and a quarter of the frames in items of 8: 27.1 -> 25.8 and
+            // 99.7 -> 96.6 ms at 1162x1008, 178.1 -> 169.7 ms (128 frames) at 1920x1080.
+            unsigned fine_frames = 0, fine_chunk = 0;
+            const bool two_tiers = use_dual && !kn.chunk && kn.fine_items > 0;
+            // frames per long item, the short tier's frames and item length (fine[2]) for a number of long items per lane; returns the launch's items
+            auto tiers = [&](unsigned long long coarse_items, unsigned long long &c_out, unsigned *fine) -> unsigned long long {
+                const unsigned fc = kn.fine_chunk > 0 ? (unsigned)kn.fine_chunk : std::min(8u, std::max(2u, cnt / 16u));
+                unsigned fr = 0;
+                if ((unsigned long long)n_slots < 16ull * lanes) {
+                    // short items per pixel so that a lane gets about kn.fine_items of them; at most half of the frames
+                    const unsigned long long per_pixel = ((unsigned long long)kn.fine_items * lanes + n_slots - 1) / n_slots;
+                    fr = (unsigned)std::min<unsigned long long>(per_pixel * fc, (cnt / 2u) / fc * fc);
+                }
+                if (fr < fc) fr = 0;
+                const unsigned coarse = cnt - fr;
+                unsigned long long c = ((unsigned long long)coarse * n_slots) / (lanes * coarse_items);
+                c = std::max<unsigned long long>(c, std::max(fc + 1u, (unsigned)kn.dual_min_chunk));
+                c = std::min<unsigned long long>(c, coarse);
+                const unsigned long long parts = (coarse + c - 1) / c;
+                c_out = (coarse + parts - 1) / parts;                // equal parts of the long tier
+                fine[0] = fr; fine[1] = fr ? fc : 0u;
+                return (unsigned long long)n_slots * (parts + (fr ? fr / fc : 0u));
+            };
             // With few items per lane the launch ends ragged unless the expensive pixels go first; with
             // many, image order (neighbouring pixels, similar paths in a wave) is the better order.
-            const unsigned long long items = (unsigned long long)n_slots * ((cnt + chunk - 1) / chunk);
+            unsigned long long items = (unsigned long long)n_slots * ((cnt + chunk - 1) / chunk);
+            unsigned long long long_chunk = chunk;
+            unsigned long_fine[2] = {0, 0};
+            if (two_tiers) items = tiers((unsigned long long)kn.coarse_items, long_chunk, long_fine);
             // (an overlapped call keeps image order: the cost keys and their sort belong to the context's stream)
             const bool ordered = !region && !kn.no_order && items < 32ull * lanes && ctx->pipe_active < 0;
+            if (two_tiers) {
+                if (ordered && ctx->order_valid) { chunk = long_chunk; fine_frames = long_fine[0]; fine_chunk = long_fine[1]; }
+                else { unsigned f2[2]; (void)tiers(16ull, chunk, f2); fine_frames = f2[0]; fine_chunk = f2[1]; }
+            }
             if (!ordered && !region) ctx->order_valid = false;
             const uint32_t *order = region ? ctx->d_okeys[1] : (ctx->order_valid ? ctx->d_ovals[0] : (const uint32_t *)nullptr);
             PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
@@ -2372,20 +2411,11 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
                 (uint32_t)chunk, tune, top, threads, xstack); } while (0)
             // slot of the variant in ctx->lds_attr: COUNT, LDSN, NEAR as bits; + 10 with pair lines, + 16 / + 22 for trees with
             // explicit child ids (without / with pair lines); 8, 9: wavefront; 28, 29: the per-ray kernels
-            // two paths per lane need items of several frames (the two paths are two frames of one pixel): short launches,
-            // whose items are one or two frames, run the single-path kernel
-            if ((lds_nodes || (!gen && !use_pair)) && !near_first && kn.dual && chunk >= (unsigned long long)kn.dual_min_chunk) {
+            if (use_dual) {
                 // k_trace_dual: slots 30, 31 (tree in LDS), 18, 19 (plain records from global memory)
                 Tuning dt = tune;
-                if (kn.fine_frac > 0 && kn.fine_chunk >= 1 && !kn.chunk) {
-                    // the last 1/fine_frac of the launch's frames in short items
-                    unsigned fine = cnt / (unsigned)kn.fine_frac;
-                    fine -= fine % (unsigned)kn.fine_chunk;
-                    if (fine >= (unsigned)kn.fine_chunk && cnt - fine >= chunk && (unsigned)kn.fine_chunk < chunk) {
-                        dt.fine_frames = (int)fine;
-                        dt.fine_chunk = kn.fine_chunk;
-                    }
-                }
+                dt.fine_frames = (int)fine_frames;
+                dt.fine_chunk = (int)fine_chunk;
                 dt.refill_t = kn.dual_refill_t;
                 dt.leaf_t = kn.dual_leaf_t;
 #define PT_LAUNCH_DUAL(SLOT, C, L) do { \
