@@ -1033,7 +1033,7 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
     uint32_t work_start = 0, iterations = 0;
     // the lane's two paths (seed, bounce count, local frame, throughput); path `act` owns the traversal slot, the other
     // one the parked slot.  Only the shading code reads or writes them.
-    uint32_t sd0 = 0, sd1 = 0, fl0 = 0, fl1 = 0;
+    uint32_t sd0 = 0, sd1 = 0, fl0 = 0, fl1 = 0, px0 = 0, px1 = 0;
     int it0 = 1, it1 = 1, act = 0;
     pt_f3 mu0 = pt_mk3(0, 0, 0), mu1 = mu0;
     // traversal slot: cur_k >= K_POP: traversing; K_IDLE: its ray is finished, the result is still here; K_EMPTY / K_NOITEM: no path
@@ -1050,8 +1050,9 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
     pt_f3 p_o = pt_mk3(0, 0, 0), p_d = pt_mk3(0, 0, 1);
     float p_q0 = 0, p_q1 = 0, p_q2 = 0;
 
-    auto emit = [&](const pt_f3 &color, uint32_t fl) {
-        put_sample(samples, (size_t)px * count + fl, color.x, color.y, color.z);
+    // (a path carries its pixel: the lane may have gone on to its next item while the path is still in flight)
+    auto emit = [&](const pt_f3 &color, unsigned pixel, uint32_t fl) {
+        put_sample(samples, (size_t)pixel * count + fl, color.x, color.y, color.z);
     };
     // The finished ray of the traversal slot (if any) moves to the parked slot, its origin advanced to the hit point
     // (ray_tracing.hlsl:376); the parked ray (if any) moves to the traversal slot.  For lanes that are not traversing and
@@ -1090,7 +1091,9 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
             const long long t_refill = COUNT ? (long long)__builtin_readcyclecounter() : 0;
             for (int pass = 0; pass < 2; pass++) {
                 // ---- take new pixels
-                bool want = cur_k == K_NOITEM && !exhausted;
+                // a lane asks for its next item as soon as the current one has no frame left to start, while that item's last
+                // paths are still in flight: otherwise an item would end on a lone path, with nothing parked beside it
+                bool want = f == f_end && !exhausted;
                 unsigned long long wm = ballot64(want);
                 while (wm != 0) {
                     if (q_next == q_end) {
@@ -1116,6 +1119,7 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
                             f = coarse_frames + (j - slot * fine_chunks) * fine_chunk;
                             f_end = min(f + fine_chunk, count);
                         }
+                        if (cur_k != K_NOITEM && pixel_work && iterations != work_start) atomicAdd(&pixel_work[px], iterations - work_start);
                         px = order ? order[slot] : slot;
                         work_start = iterations;
                         const uchar4 dif8 = reinterpret_cast<const uchar4 *>(diffuse_tex)[px];
@@ -1124,15 +1128,16 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
                         matid0 = mat_slot(__float_as_int(nrm4.w) - 1);  // asint(normal.w) - 1
                         if (__float_as_int(nrm4.w) <= 0) {
                             // ray_tracing.hlsl:361-362: black, but still accumulated every frame
-                            for (uint32_t k = f; k < f_end; k++) { cnt.paths++; emit(pt_mk3(0, 0, 0), k); }
+                            for (uint32_t k = f; k < f_end; k++) { cnt.paths++; emit(pt_mk3(0, 0, 0), px, k); }
+                            f = f_end;
                         } else {
                             hit_pos = pt_mk3(pos4.x, pos4.y, pos4.z);
                             multi0 = pt_mk3(dif8.x / 255.0f, dif8.y / 255.0f, dif8.z / 255.0f);
                             if (mats[3 * matid0].y > 1) multi0 = pt_mk3(1, 1, 1);
                             view0 = pt_normalize3(pt_sub3(hit_pos, g_pos));
                             normal0 = pt_normalize3(pt_mk3(nrm4.x, nrm4.y, nrm4.z));
-                            cur_k = K_EMPTY;
-                            p_state = P_START;              // an item has at least one frame
+                            if (cur_k == K_NOITEM) cur_k = K_EMPTY;
+                            if (p_state == P_NONE) p_state = P_START;          // an item has at least one frame
                             want = false;
                         }
                     }
@@ -1145,7 +1150,7 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
                 // frame's path; ONE pass of the shading code for all of them
                 if ((p_state & 1) == 0) {
                     // the parked path is the one that does not own the traversal slot
-                    uint32_t p_seed = act ? sd0 : sd1, p_fl = act ? fl0 : fl1;
+                    uint32_t p_seed = act ? sd0 : sd1, p_fl = act ? fl0 : fl1, p_px = act ? px0 : px1;
                     int p_itr = act ? it0 : it1;
                     pt_f3 p_multi = pt_mk3(act ? mu0.x : mu1.x, act ? mu0.y : mu1.y, act ? mu0.z : mu1.z);
                     pt_f3 direction;
@@ -1177,7 +1182,7 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
                             }
                         }
                         if (ended) {
-                            emit(pt_mk3(0, 0, 0), p_fl);
+                            emit(pt_mk3(0, 0, 0), p_px, p_fl);
                             p_state = f < f_end ? P_START : P_NONE;
                         }
                     }
@@ -1189,6 +1194,7 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
                         p_itr = 1;
                         p_o = hit_pos;
                         p_fl = f;
+                        p_px = px;
                         f++;
                         p_state = P_DONE;           // a path is in the slot (the outcome below decides its state)
                         bounce = true;
@@ -1197,7 +1203,7 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
                         if (get_bounce(mats, lds_matq, first_frame + p_fl, b_view, b_normal, b_mat, p_multi, direction, p_seed)) {
                             cont = true;
                         } else {
-                            emit(p_multi, p_fl);
+                            emit(p_multi, p_px, p_fl);
                             p_state = f < f_end ? P_START : P_NONE;
                         }
                     }
@@ -1217,8 +1223,8 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
                             p_q0 = __int_as_float(-1);
                         }
                     }
-                    if (act) { sd0 = p_seed; fl0 = p_fl; it0 = p_itr; mu0 = p_multi; }
-                    else     { sd1 = p_seed; fl1 = p_fl; it1 = p_itr; mu1 = p_multi; }
+                    if (act) { sd0 = p_seed; fl0 = p_fl; px0 = p_px; it0 = p_itr; mu0 = p_multi; }
+                    else     { sd1 = p_seed; fl1 = p_fl; px1 = p_px; it1 = p_itr; mu1 = p_multi; }
                 }
                 if ((cur_k == K_IDLE || cur_k == K_EMPTY) && p_state == P_READY) exchange(true);
                 // ---- items whose frames are all done
@@ -2345,7 +2351,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             // many per lane already).  Long items need the expensive pixels first: a launch without a cost order from its
             // predecessors keeps the sixteen items per lane of the single-path kernel.  Measured on scene04, 32 / 128 frames per
             // launch, against sixteen long items per lane and a quarter of the frames in items of 8: 27.1 -> 25.8 and
-            // 99.7 -> 96.6 ms at 1162x1008, 178.1 -> 169.7 ms (128 frames) at 1920x1080.
+            // 98.1 -> 96.3 ms at 1162x1008, 178.1 -> 169.7 ms (128 frames) at 1920x1080.
             unsigned fine_frames = 0, fine_chunk = 0;
             const bool two_tiers = use_dual && !kn.chunk && kn.fine_items > 0;
             // frames per long item, the short tier's frames and item length (fine[2]) for a number of long items per lane; returns the launch's items
