@@ -103,7 +103,7 @@ struct Knobs {
     int chunk = 0;                      // PTAMD_CHUNK: frames per work item
     int print_sched = 0;                // PTAMD_PRINT_SCHED: scheduling statistics on stderr
     int dual = 1;                       // PTAMD_DUAL: two paths per lane for trees in LDS (k_trace_dual); 0: k_trace_persistent
-    int dual_min_chunk = 4;             // PTAMD_DUAL_MIN_CHUNK: frames per work item from which k_trace_dual is used
+    int dual_min_chunk = 1;             // PTAMD_DUAL_MIN_CHUNK: k_trace_dual is used when a launch cut into sixteen items per lane has items of at least this many frames (1: always)
     int dual_refill_t = 8, swap_t = 4, shade_t = 48, dual_leaf_t = 8;   // PTAMD_DUAL_REFILL_T, PTAMD_SWAP_T, PTAMD_SHADE_T, PTAMD_DUAL_LEAF_T: its wave-vote thresholds
     int no_top_levels = 0;              // PTAMD_NO_TOP_LEVELS: trees in global memory without their upper levels in LDS
     int gen_lds_entries = 0;            // PTAMD_GEN_LDS_ENTRIES: cap of the LDS part of the explicit traversal stack (0: what fits)

@@ -2341,8 +2341,9 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             if (chunk > cnt) chunk = cnt;
             chunk = (cnt + (cnt + chunk - 1) / chunk - 1) / ((cnt + chunk - 1) / chunk);
             if (kn.chunk > 0) { chunk = (unsigned long long)kn.chunk; if (chunk > cnt) chunk = cnt; }
-            // two paths per lane need items of several frames (the two paths are two frames of one pixel): short launches,
-            // whose items are one or two frames, run the single-path kernel
+            // two paths per lane (k_trace_dual) for every launch length: a path carries its pixel, so a lane's two paths may be
+            // two frames of one item or frames of two items (kn.dual_min_chunk > 1 keeps the single-path kernel for launches
+            // whose sixteen-per-lane items would be shorter than that)
             const bool use_dual = (lds_nodes || (!gen && !use_pair)) && !near_first && kn.dual && chunk >= (unsigned long long)kn.dual_min_chunk;
             // k_trace_dual hands a launch's frames out in two tiers.  An item's end costs (its last path runs without a second
             // one to switch to, and the next item's pixel has to be fetched), so every pixel's first frames come in few long
