@@ -598,8 +598,12 @@ def main():
     bytes_per_ray = visits_per_ray * BYTES_PER_VISIT + tris_per_ray * BYTES_PER_TRI_TEST
 
     note("statistics block traced")
+    ctx.set_trace_timing(True)      # HIP events around the trace kernel of every launch, on the library's stream
     for s in range(args.warmup):
         step(s)
+    # (the first launches differ from the steady state: no per-pixel cost order yet, cold code; they are reported on their
+    # own so that a profiler's per-kernel average over ALL launches of the run can be checked against the line)
+    warm_ms = ctx.trace_times()
     if world > 1:
         torch.cuda.synchronize()
         note("warm-up traced")
@@ -610,7 +614,6 @@ def main():
         note("warm-up reduce done")
     ctx.reset_accumulation()
     ctx.reset_counters()
-    ctx.set_trace_timing(True)      # HIP events around the trace kernel of every launch, on the library's stream
 
     if world > 1:
         dist.barrier()
@@ -651,6 +654,8 @@ def main():
     else:
         roofline = trace_roofline_scene(kern_avg_ms, rays_per_launch, bytes_per_ray, len(kern_ms) // args.steps,
                                         PROFILE_TRACE.get((args.scene, W, H, fpb)) if len(kern_ms) == args.steps else None)
+
+    roofline["warmup_launch_ms"] = [round(float(x), 3) for x in warm_ms]
 
     builds = {}
     if not args.no_build and not soup_mode:
