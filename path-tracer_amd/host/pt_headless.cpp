@@ -21,6 +21,8 @@ int main(int argc, char **argv)
     // nobody looks at the image between frames here: queue four stratification cycles per launch (the class's default of 32
     // suits an interactive caller); snapshots and the final image flush the queue
     ray_tracer.frames_per_launch = 128;
+    // (PT_HEADLESS_FRAMES_PER_LAUNCH: another queue length, e.g. 32, the class's default, or 1, the reference's own loop)
+    if (const char *e = std::getenv("PT_HEADLESS_FRAMES_PER_LAUNCH")) { if (std::atoi(e) >= 1) ray_tracer.frames_per_launch = std::atoi(e); }
     ray_tracer.loadScene(argv[1]);
     ray_tracer.loadShaders();
     ray_tracer.createBuffers();
