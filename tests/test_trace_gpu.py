@@ -493,6 +493,28 @@ def test_full_size_two_paths_per_lane_with_and_without_extra_waves(gpu_ctx_facto
     assert ctx.counters() == tot
 
 
+def test_full_size_launch_after_the_cost_order_exists(gpu_ctx_factory, golden):
+    """Two launches of other frames first: the third then has the per-pixel cost order, so k_trace_dual hands every pixel's
+    frames out as one long item, expensive pixels first, and lanes fetch their next item while the last paths of the
+    current one are in flight.  scene04 at 1162x1008, every pixel of three frames and all counters against the oracle."""
+    W, H = 1162, 1008
+    ctx = gpu_ctx_factory()
+    sc, gb, _ = _setup(ctx, golden["scene04"], W, H)
+    for first in (0, 16):
+        ctx.trace_frames(first, ptamd.frame_seeds(1, first, 16), ptamd.PT_ACCUM_LINEAR)
+    ctx.reset_accumulation(); ctx.reset_counters()
+    seeds = ptamd.frame_seeds(1, 77, 3)
+    ctx.set_detailed_counters(True)
+    ctx.trace_frames(77, seeds, ptamd.PT_ACCUM_LINEAR)
+    acc = np.zeros((H, W, 4), np.float32)
+    tot = dict(paths=0, rays=0, node_visits=0, box_tests=0, tri_tests=0)
+    for f in range(3):
+        c = orc.trace_frame_linear(sc, gb, 77 + f, seeds[f], acc)
+        tot = {k: tot[k] + c[k] for k in tot}
+    assert np.array_equal(_bits(ctx.linear_sum()), _bits(acc))
+    assert ctx.counters() == tot
+
+
 def test_full_size_many_frames_properties(gpu_ctx_factory, golden):
     """scene04, 1162x1008, 256 frames: the same frames as one launch, as eight launches, under
     both schedules and in literal vs linear mode; linear alpha counts the samples; modes agree to the documented tolerance."""
