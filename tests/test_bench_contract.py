@@ -124,3 +124,21 @@ def test_bench_without_a_launcher_starts_the_ranks_itself():
     import torch
     if not torch.cuda.is_available():
         assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_committed_records_belong_to_the_kernel_sources_in_the_tree():
+    """Every r03 counter summary and bench line under profiles/ was taken with the kernel sources of this tree (the hash
+    bench.py prints): after a kernel edit the records have to be collected again (scripts/gpu_collect_profiles.sh)."""
+    import glob
+    sys.path.insert(0, ROOT)
+    import bench
+    h = bench.sources_hash()
+    summaries = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*_pmc.json")))
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_bench_*.json")))
+    assert len(summaries) >= 9 and len(lines) >= 6
+    for f in summaries:
+        assert json.load(open(f))["_meta"]["sources_sha256_16"] == h, f
+    for f in lines:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        assert d["kernel_sources_sha256_16"] == h, f
+        assert d["roofline"]["profile"]["taken_with_these_kernel_sources"] is True, f
