@@ -48,6 +48,7 @@ static void read_knobs(Knobs &k)
     k.dual_leaf_t = env_int("PTAMD_DUAL_LEAF_T", k.dual_leaf_t, 1, 64);
     k.sort_chained = env_int("PTAMD_SORT_CHAINED", k.sort_chained, 0, 1);
     k.fine_items = env_int("PTAMD_FINE_ITEMS", k.fine_items, 0, 1 << 20);
+    k.seeds_ahead = env_int("PTAMD_SEEDS_AHEAD", k.seeds_ahead, 0, 1);
     k.coarse_items = env_int("PTAMD_COARSE_ITEMS", k.coarse_items, 1, 1 << 20);
     k.fine_chunk = env_int("PTAMD_FINE_CHUNK", k.fine_chunk, 0, 1 << 20);
     k.extra_wave = env_int("PTAMD_EXTRA_WAVES", k.extra_wave, 0, 16);      // a workgroup has at most 16 waves
@@ -201,6 +202,12 @@ void pt_destroy(pt_context *ctx)
         if (ctx->seed_ev[k]) (void)hipEventDestroy(ctx->seed_ev[k]);
     }
     free_pipe(ctx);
+    if (ctx->ahead.stream) { (void)hipStreamSynchronize(ctx->ahead.stream); (void)hipStreamDestroy(ctx->ahead.stream); }
+    for (int b = 0; b < 2; b++) {
+        dev_free(ctx->ahead.d_frame_seeds[b]); dev_free(ctx->ahead.d_path_seeds[b]);
+        if (ctx->ahead.ready[b]) (void)hipEventDestroy(ctx->ahead.ready[b]);
+        if (ctx->ahead.released[b]) (void)hipEventDestroy(ctx->ahead.released[b]);
+    }
     free_build(ctx);
     free_images(ctx);
     if (ctx->prims_owned) { void *p = const_cast<pt_PrimitiveRender *>(ctx->d_prims); if (p) (void)hipFree(p); }
@@ -645,6 +652,46 @@ static int trace_frames(pt_context *ctx, const char *who, uint32_t first_frame, 
         ctx->pipe_active = i;
     }
     Swap swap(ctx, sl);
+    // a long call on the context's own stream: its path seeds are computed on a stream of the library's while the previous
+    // call's trace kernel runs (pt_context::SeedsAhead)
+    if (!overlapped && ctx->overlap && !ctx->user_stream && !region && ptk_seeds_ahead_ok(ctx, count)) {
+        pt_context::SeedsAhead &a = ctx->ahead;
+        const int b = a.next;
+        a.next ^= 1;
+        if (!a.stream) PT_HIP(ctx, hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking));
+        if (!a.ready[b]) PT_HIP(ctx, hipEventCreateWithFlags(&a.ready[b], hipEventDisableTiming));
+        if (!a.released[b]) PT_HIP(ctx, hipEventCreateWithFlags(&a.released[b], hipEventDisableTiming));
+        const size_t paths = (size_t)ctx->W * ctx->H * count;
+        if (a.frame_cap[b] < count || a.path_cap[b] < paths) {
+            // (the set's last reader, a trace kernel on the context's stream, has to be done before the buffers go)
+            PT_HIP(ctx, hipStreamSynchronize(a.stream));
+            PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            dev_free(a.d_frame_seeds[b]); dev_free(a.d_path_seeds[b]);
+            a.frame_cap[b] = 0; a.path_cap[b] = 0; a.released_used[b] = false;
+            if (int rc = dev_alloc(ctx, &a.d_frame_seeds[b], (size_t)count)) return rc;
+            if (int rc = dev_alloc(ctx, &a.d_path_seeds[b], paths)) return rc;
+            a.frame_cap[b] = count; a.path_cap[b] = paths;
+        }
+        if (a.released_used[b]) PT_HIP(ctx, hipStreamWaitEvent(a.stream, a.released[b], 0));
+        const int slot = ctx->seed_slot;
+        ctx->seed_slot = (slot + 1) % PT_SEED_SLOTS;
+        if (ctx->seed_ev_used[slot]) PT_HIP(ctx, hipEventSynchronize(ctx->seed_ev[slot]));
+        std::memcpy(ctx->h_seeds[slot], seeds, (size_t)count * sizeof(uint32_t));
+        PT_HIP(ctx, hipMemcpyAsync(a.d_frame_seeds[b], ctx->h_seeds[slot], (size_t)count * sizeof(uint32_t), hipMemcpyHostToDevice, a.stream));
+        PT_HIP(ctx, hipEventRecord(ctx->seed_ev[slot], a.stream));
+        ctx->seed_ev_used[slot] = true;
+        if (int rc = ptk_path_seeds_ahead(ctx, a.stream, count, a.d_frame_seeds[b], a.d_path_seeds[b])) return rc;
+        PT_HIP(ctx, hipEventRecord(a.ready[b], a.stream));
+        PT_HIP(ctx, hipStreamWaitEvent(ctx->stream, a.ready[b], 0));
+        ctx->path_seeds = a.d_path_seeds[b];
+        const int rc = ptk_trace_frames(ctx, first_frame, count, mode, region);
+        ctx->path_seeds = nullptr;
+        if (rc) return rc;
+        PT_HIP(ctx, hipEventRecord(a.released[b], ctx->stream));
+        a.released_used[b] = true;
+        ctx->frame_count = first_frame + count;
+        return PT_OK;
+    }
     if (ctx->seeds_cap < count) {
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         dev_free(ctx->d_seeds);

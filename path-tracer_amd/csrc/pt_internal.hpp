@@ -104,6 +104,7 @@ struct Knobs {
     int print_sched = 0;                // PTAMD_PRINT_SCHED: scheduling statistics on stderr
     int dual = 1;                       // PTAMD_DUAL: two paths per lane for trees in LDS (k_trace_dual); 0: k_trace_persistent
     int dual_min_chunk = 1;             // PTAMD_DUAL_MIN_CHUNK: k_trace_dual is used when a launch cut into sixteen items per lane has items of at least this many frames (1: always)
+    int seeds_ahead = 1;                // PTAMD_SEEDS_AHEAD: path seeds of long calls on trees in LDS computed on an internal stream while the previous trace kernel runs (0: in line)
     int dual_refill_t = 8, swap_t = 4, shade_t = 48, dual_leaf_t = 8;   // PTAMD_DUAL_REFILL_T, PTAMD_SWAP_T, PTAMD_SHADE_T, PTAMD_DUAL_LEAF_T: its wave-vote thresholds
     int no_top_levels = 0;              // PTAMD_NO_TOP_LEVELS: trees in global memory without their upper levels in LDS
     int gen_lds_entries = 0;            // PTAMD_GEN_LDS_ENTRIES: cap of the LDS part of the explicit traversal stack (0: what fits)
@@ -232,6 +233,20 @@ struct pt_context {
     bool user_stream = false;         // pt_set_stream gave a stream of the caller's: no overlap (its own kernels are not seen here)
     int overlap = 1;                  // pt_set_trace_overlap
     uint32_t h_seeds_cap = 0;         // seeds the pinned staging buffers hold
+    // Seeds ahead: the path seeds of a long call (16-round hash per path, no memory to speak of) are computed on a stream of
+    // the library's own, into a plain array, while the PREVIOUS call's trace kernel still runs: that kernel's waves leave a
+    // SIMD's vector pipe idle about a third of the time and 32 registers per lane free, which is room for one wave of the
+    // seed kernel per SIMD.  Two sets of buffers, used in turn; the trace kernel reads the array instead of the slots' .w.
+    struct SeedsAhead {
+        hipStream_t stream = nullptr;
+        uint32_t *d_frame_seeds[2] = {nullptr, nullptr}; uint32_t frame_cap[2] = {0, 0};
+        uint32_t *d_path_seeds[2] = {nullptr, nullptr}; size_t path_cap[2] = {0, 0};
+        hipEvent_t ready[2] = {nullptr, nullptr};        // recorded on `stream` behind the seed kernel
+        hipEvent_t released[2] = {nullptr, nullptr};     // recorded on the context's stream behind the trace kernel that read the set
+        bool released_used[2] = {false, false};
+        int next = 0;
+    } ahead;
+    const uint32_t *path_seeds = nullptr;   // set while a call whose seeds were computed ahead is being enqueued
 
     // options / counters
     int stack_entries = 0;            // 0 = automatic
@@ -262,6 +277,8 @@ int ptk_export_sorted(pt_context *ctx, pt_PrimitiveRayCS *d_out);
 int ptk_export_tree(pt_context *ctx);
 int ptk_primary(pt_context *ctx, const pt_camera *cam, const uint8_t *d_albedo);
 int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int mode, const int *region);
+bool ptk_seeds_ahead_ok(const pt_context *ctx, uint32_t count);
+int ptk_path_seeds_ahead(pt_context *ctx, hipStream_t stream, uint32_t count, const uint32_t *d_frame_seeds, uint32_t *d_path_seeds);
 bool ptk_tree_in_lds(const pt_context *ctx);
 bool ptk_short_calls_may_overlap(const pt_context *ctx);
 int ptk_resolve(pt_context *ctx);

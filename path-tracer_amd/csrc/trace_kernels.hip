@@ -61,11 +61,31 @@ __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builti
 struct Staging {
     float4 *__restrict__ slot;
 };
-__device__ __forceinline__ void put_sample(const Staging &st, size_t path, float r, float g, float b)
+// The same for the kernel variants that may be handed their seeds in an array of their own, [pixel][frame], computed ahead of
+// the launch (trees in LDS).  A type of its own, so that the other variants keep their argument list and their code: the
+// variant with child lines runs at the register limit, and its allocation turns with anything that is added to it.
+struct StagingAhead {
+    float4 *__restrict__ slot;
+    const uint32_t *__restrict__ seeds;     // or null: the seed is in the slot's .w
+};
+template <bool LDSN> struct StagingOf {
+    typedef Staging type;
+    static const Staging &pick(const Staging &a, const StagingAhead &) { return a; }
+};
+template <> struct StagingOf<true> {
+    typedef StagingAhead type;
+    static const StagingAhead &pick(const Staging &, const StagingAhead &b) { return b; }
+};
+template <typename ST>
+__device__ __forceinline__ void put_sample(const ST &st, size_t path, float r, float g, float b)
 {
     st.slot[path] = make_float4(r, g, b, 1.0f);
 }
 __device__ __forceinline__ uint32_t path_seed(const Staging &st, size_t path) { return __float_as_uint(st.slot[path].w); }
+__device__ __forceinline__ uint32_t path_seed(const StagingAhead &st, size_t path)
+{
+    return st.seeds ? st.seeds[path] : __float_as_uint(st.slot[path].w);
+}
 
 struct LaneCounters {
     unsigned paths = 0, rays = 0, node_visits = 0, box_tests = 0, tri_tests = 0;
@@ -375,7 +395,7 @@ struct TopLevels { int k0, nodes; int off[33]; };    // itr_limit: a path ends w
 // nearly every refill round for the few lanes that start a path, here every lane does useful work.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_path_seeds(int W, unsigned npix, uint32_t count, const uint32_t *__restrict__ seeds,
-                                                    Staging samples, int frame_lanes_log2)
+                                                    Staging samples, int frame_lanes_log2, uint32_t *__restrict__ array)
 {
     // A workgroup covers 256 >> frame_lanes_log2 pixels; the lanes of a pixel stride over its frames, so a
     // pixel's slots are written side by side and no index needs a division by `count`.
@@ -385,8 +405,11 @@ __global__ __launch_bounds__(256) void k_path_seeds(int W, unsigned npix, uint32
         const unsigned y = px / (unsigned)W, x = px - y * (unsigned)W;
         // ray_tracing.hlsl:410: uint(launchIndex.x + launchIndex.y * viewportDims.x), in float
         const uint32_t pixel_id = (uint32_t)((float)x + (float)y * (float)W);
-        for (unsigned fl = fl0; fl < count; fl += frame_lanes)
-            samples.slot[(size_t)px * count + fl] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rand_init(pixel_id, seeds[fl])));
+        for (unsigned fl = fl0; fl < count; fl += frame_lanes) {
+            const uint32_t seed = rand_init(pixel_id, seeds[fl]);
+            if (array) array[(size_t)px * count + fl] = seed;
+            else samples.slot[(size_t)px * count + fl] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(seed));
+        }
     }
 }
 
@@ -446,7 +469,7 @@ __device__ __forceinline__ void persistent_paths(const SceneView sc, const TriIs
                                                  const float4 *__restrict__ world_tex,
                                                  const uint32_t first_frame, const uint32_t count,
                                                  const uint32_t *__restrict__ seeds,
-                                                 const Staging samples, DevCounters *__restrict__ counters,
+                                                 const typename StagingOf<LDSN>::type samples, DevCounters *__restrict__ counters,
                                                  unsigned *__restrict__ work_counter,
                                                  const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
                                                  const uint32_t chunk, const Tuning tune, const TopLevels top,
@@ -903,7 +926,7 @@ __global__ __launch_bounds__(1024) void k_trace_persistent(SceneView sc, const T
                                                     const float4 *__restrict__ world_tex,
                                                     uint32_t first_frame, uint32_t count,
                                                     const uint32_t *__restrict__ seeds,
-                                                    const Staging samples, DevCounters *__restrict__ counters,
+                                                    const typename StagingOf<LDSN>::type samples, DevCounters *__restrict__ counters,
                                                     unsigned *__restrict__ work_counter,
                                                     const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
                                                     uint32_t chunk, Tuning tune, TopLevels top, int lds_threads, float *__restrict__ xstack)
@@ -992,7 +1015,7 @@ __device__ __forceinline__ void dual_paths(const SceneView &sc, const TriIsect *
                                            const float4 *__restrict__ normal_tex,
                                            const float4 *__restrict__ world_tex,
                                            const uint32_t first_frame, const uint32_t count,
-                                           const Staging samples, DevCounters *__restrict__ counters,
+                                           const typename StagingOf<LDSN>::type samples, DevCounters *__restrict__ counters,
                                            unsigned *__restrict__ work_counter,
                                            const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
                                            const uint32_t chunk, const Tuning &tune, const TopLevels &top,
@@ -1371,7 +1394,7 @@ __global__ __launch_bounds__(1024) void k_trace_dual(SceneView sc, const TriIsec
                                               const float4 *__restrict__ normal_tex,
                                               const float4 *__restrict__ world_tex,
                                               uint32_t first_frame, uint32_t count,
-                                              const Staging samples, DevCounters *__restrict__ counters,
+                                              const typename StagingOf<LDSN>::type samples, DevCounters *__restrict__ counters,
                                               unsigned *__restrict__ work_counter,
                                               const uint32_t *__restrict__ order, uint32_t *__restrict__ pixel_work,
                                               uint32_t chunk, Tuning tune, TopLevels top, int lds_threads, float *__restrict__ xstack)
@@ -2123,6 +2146,26 @@ bool ptk_short_calls_may_overlap(const pt_context *ctx)
     return ptk_tree_in_lds(ctx) || !uses_child_lines(ctx);
 }
 
+// A call whose path seeds may be computed ahead (pt_context::SeedsAhead): persistent schedule, tree in LDS (trees in global
+// memory keep the seed in the sample slot: the seed read brings the slot's address translation in), one launch for the call.
+bool ptk_seeds_ahead_ok(const pt_context *ctx, uint32_t count)
+{
+    return ctx->knobs.seeds_ahead && ctx->schedule == PT_SCHEDULE_PERSISTENT && ptk_tree_in_lds(ctx) &&
+           frames_per_launch(ctx, count, false) >= count;
+}
+
+int ptk_path_seeds_ahead(pt_context *ctx, hipStream_t stream, uint32_t count, const uint32_t *d_frame_seeds, uint32_t *d_path_seeds)
+{
+    const size_t npix = (size_t)ctx->W * ctx->H;
+    int frame_lanes_log2 = 0;
+    while (frame_lanes_log2 < 8 && (2u << frame_lanes_log2) <= count) frame_lanes_log2++;
+    const Staging none = {nullptr};
+    hipLaunchKernelGGL(k_path_seeds, dim3((unsigned)ctx->num_cus * 16u), dim3(256), 0, stream, ctx->W, (unsigned)npix, count,
+                       d_frame_seeds, none, frame_lanes_log2, d_path_seeds);
+    PT_HIP(ctx, hipGetLastError());
+    return PT_OK;
+}
+
 bool ptk_tree_in_lds(const pt_context *ctx)
 {
     int levels = 0;
@@ -2257,6 +2300,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
         ctx->samples_frames = per_launch;
     }
     const Staging staging = {ctx->d_samples};
+    const StagingAhead staging_ahead = {ctx->d_samples, ctx->path_seeds};
     if (wavefront && ctx->wf_paths < (size_t)per_launch * npix) {
         PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int k = 0; k < 2; k++) { if (ctx->d_wf_queue[k]) (void)hipFree(ctx->d_wf_queue[k]); ctx->d_wf_queue[k] = nullptr; }
@@ -2395,8 +2439,9 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             PT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned), ctx->stream));
             int frame_lanes_log2 = 0;                    // lanes per pixel: the largest power of two <= count, at most 256
             while (frame_lanes_log2 < 8 && (2u << frame_lanes_log2) <= cnt) frame_lanes_log2++;
-            hipLaunchKernelGGL(k_path_seeds, dim3((unsigned)ctx->num_cus * 16u), dim3(256), 0, ctx->stream, ctx->W, (unsigned)npix, cnt,
-                               seeds, staging, frame_lanes_log2);
+            if (!ctx->path_seeds)
+                hipLaunchKernelGGL(k_path_seeds, dim3((unsigned)ctx->num_cus * 16u), dim3(256), 0, ctx->stream, ctx->W, (unsigned)npix, cnt,
+                               seeds, staging, frame_lanes_log2, (uint32_t *)nullptr);
             // A tree in LDS leaves stack room for `threads` lanes; the waves up to 1024 threads (scene04: one, the sixteenth)
             // run too, with their stack entries in global memory: 115 -> 109 ms per 128 frames of scene04.
             int xthreads = (lds_nodes && !kn.max_threads) ? 1024 - threads : 0;       // (PTAMD_MAX_THREADS asks for FEWER waves)
@@ -2417,7 +2462,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
             if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream)); \
             hipLaunchKernelGGL((k_trace_persistent<C, L, N, P, G>), dim3(grid), dim3(threads + ((L) ? xthreads : 0)), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
                 ctx->d_gstack, n_slots, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, seeds, \
-                staging, ctx->d_counters, ctx->d_work, \
+                StagingOf<(L)>::pick(staging, staging_ahead), ctx->d_counters, ctx->d_work, \
                 order, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, \
                 (uint32_t)chunk, tune, top, threads, xstack); } while (0)
             // slot of the variant in ctx->lds_attr: COUNT, LDSN, NEAR as bits; + 10 with pair lines, + 16 / + 22 for trees with
@@ -2433,7 +2478,7 @@ int ptk_trace_frames(pt_context *ctx, uint32_t first_frame, uint32_t count, int 
                 if (int rc_ = ensure_lds_limit(ctx, SLOT, &k_trace_dual<C, L>, lds_bytes)) return rc_; \
                 if (ev_begin) PT_HIP(ctx, hipEventRecord(ev_begin, ctx->stream)); \
                 hipLaunchKernelGGL((k_trace_dual<C, L>), dim3(grid), dim3(threads + xthreads), lds_bytes, ctx->stream, sv, ctx->d_tri_sorted, levels, \
-                    n_slots, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, staging, ctx->d_counters, ctx->d_work, \
+                    n_slots, ctx->d_diffuse, ctx->d_normal, ctx->d_world, first, cnt, StagingOf<(L)>::pick(staging, staging_ahead), ctx->d_counters, ctx->d_work, \
                     order, ordered ? ctx->d_pixel_work : (uint32_t *)nullptr, (uint32_t)chunk, dt, top, threads, xstack); } while (0)
                 if (lds_nodes) { if (ctx->detailed) PT_LAUNCH_DUAL(31, true, true); else PT_LAUNCH_DUAL(30, false, true); }
                 else           { if (ctx->detailed) PT_LAUNCH_DUAL(19, true, false); else PT_LAUNCH_DUAL(18, false, false); }

@@ -708,6 +708,39 @@ def test_overlapped_short_calls_equal_serial_ones(gpu_ctx_factory, golden, monke
     assert np.array_equal(_bits(a[3]), _bits(old))
 
 
+def test_path_seeds_computed_ahead_equal_seeds_computed_in_line(gpu_ctx_factory, golden, monkeypatch):
+    """Long calls on a tree in LDS get their path seeds from an internal stream that runs ahead of the context's stream, out
+    of two buffer sets used in turn.  Calls of growing and shrinking length (the sets are reallocated), a resize, a reset
+    and a short call in between: sums and counters equal those of the same calls with the seeds computed in line."""
+    g = golden["scene01"]
+    seeds = ptamd.frame_seeds(7, 0, 200)
+    results = []
+    for ahead in ("1", "0"):
+        monkeypatch.setenv("PTAMD_SEEDS_AHEAD", ahead)
+        ctx = gpu_ctx_factory()
+        _setup(ctx, g, 320, 200)
+        snaps, f = [], 0
+        for n in (9, 16, 16, 40, 12, 64, 9):
+            ctx.trace_frames(f, seeds[f:f + n], ptamd.PT_ACCUM_LINEAR)
+            f += n
+        snaps.append((ctx.linear_sum().copy(), ctx.counters()))
+        ctx.trace(f, seeds[f])                                       # a short call between long ones
+        ctx.trace_frames(f + 1, seeds[f + 1:f + 21], ptamd.PT_ACCUM_LINEAR)
+        snaps.append((ctx.linear_sum().copy(), ctx.counters()))
+        ctx.reset_accumulation(); ctx.reset_counters()
+        ctx.trace_frames(0, seeds[0:24], ptamd.PT_ACCUM_LINEAR)
+        snaps.append((ctx.linear_sum().copy(), ctx.counters()))
+        _setup(ctx, g, 417, 233)                                     # another image size: more paths per frame than before
+        ctx.reset_counters()
+        for k in range(3):
+            ctx.trace_frames(16 * k, seeds[16 * k:16 * k + 16], ptamd.PT_ACCUM_LINEAR)
+        snaps.append((ctx.linear_sum().copy(), ctx.counters()))
+        results.append(snaps)
+    for a, b in zip(*results):
+        assert np.array_equal(_bits(a[0]), _bits(b[0])) and a[1] == b[1]
+    assert results[0][0][1]["paths"] == 320 * 200 * (9 + 16 + 16 + 40 + 12 + 64 + 9)
+
+
 def test_overlapped_single_frame_calls_at_full_size(gpu_ctx_factory, golden):
     """scene04 at 1162x1008, one frame per call (the reference's own run loop), calls overlapped on the two internal
     streams: every wave of every CU is busy, the sixteenth wave of a workgroup keeps its stack entries in global memory,
