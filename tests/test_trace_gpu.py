@@ -741,6 +741,28 @@ def test_path_seeds_computed_ahead_equal_seeds_computed_in_line(gpu_ctx_factory,
     assert results[0][0][1]["paths"] == 320 * 200 * (9 + 16 + 16 + 40 + 12 + 64 + 9)
 
 
+def test_out_of_range_knobs_are_clamped(gpu_ctx_factory, golden, monkeypatch):
+    """Tuning variables outside their ranges (negative wave counts, zero items, too many streams) are clamped when the
+    context reads them: the frames still equal the oracle's, as single-frame calls and as one long call."""
+    for k, v in (("PTAMD_EXTRA_WAVES", "-5"), ("PTAMD_FINE_CHUNK", "-3"), ("PTAMD_COARSE_ITEMS", "0"), ("PTAMD_FINE_ITEMS", "-1"),
+                 ("PTAMD_DUAL_MIN_CHUNK", "0"), ("PTAMD_PIPE_SLOTS", "99"), ("PTAMD_SHORT_GRID", "100000"), ("PTAMD_SHORT_GRID_DIV", "-2"),
+                 ("PTAMD_DUAL_REFILL_T", "0"), ("PTAMD_SHADE_T", "1000"), ("PTAMD_SWAP_T", "-1"), ("PTAMD_DUAL_LEAF_T", "0")):
+        monkeypatch.setenv(k, v)
+    W, H = 192, 144
+    ctx = gpu_ctx_factory()
+    sc, gb, _ = _setup(ctx, golden["scene04"], W, H)
+    seeds = ptamd.frame_seeds(3, 0, 12)
+    for f in range(4):
+        ctx.trace(f, seeds[f])
+    ctx.trace_frames(4, seeds[4:12], ptamd.PT_ACCUM_LITERAL)
+    ctx.trace_frames(12, ptamd.frame_seeds(3, 12, 20), ptamd.PT_ACCUM_LITERAL)
+    all_seeds = ptamd.frame_seeds(3, 0, 32)
+    old = np.zeros((H, W, 4), np.float32)
+    for f in range(32):
+        old = orc.trace_frame(sc, gb, f, all_seeds[f], old)[0]
+    assert np.array_equal(_bits(ctx.output()), _bits(old))
+
+
 def test_overlapped_single_frame_calls_at_full_size(gpu_ctx_factory, golden):
     """scene04 at 1162x1008, one frame per call (the reference's own run loop), calls overlapped on the two internal
     streams: every wave of every CU is busy, the sixteenth wave of a workgroup keeps its stack entries in global memory,
